@@ -1,0 +1,155 @@
+/* srk.h -- C ABI of the MI355X (gfx950) ESRGAN hot-path kernels.
+ *
+ * The reference (lukas-blecher/super-resolution) has no FFI: its hot path is the
+ * chain of ATen ops dispatched by /root/reference/models.py.  Each entry point
+ * below names the reference op(s) it replaces (file:line in the reference).
+ *
+ * Conventions
+ *  - all data pointers are DEVICE pointers to fp32; activations are NHWC
+ *    "views": element (n,h,w,c) of a view lives at
+ *        base[((n*H + h)*W + w) * ldc + coff + c]
+ *    so a conv can read a channel prefix / write a channel slice of a shared
+ *    dense buffer (the concat-free DenseResidualBlock, models.py:34-41).
+ *  - weights are passed PRE-PACKED (srk_pack_weights) from the canonical OIHW
+ *    fp32 nn.Conv2d parameters; the OIHW tensors stay the source of truth.
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it,
+ *    allocates nothing and never synchronises (hipGraph-capturable).
+ *  - return value: 0 = ok, negative = srk_status; nothing throws across the ABI.
+ *  - the library owns no memory: buffers and workspaces are caller-provided.
+ */
+#ifndef SRK_H
+#define SRK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRK_VERSION 100
+
+typedef enum srk_status {
+  SRK_OK = 0,
+  SRK_ERR_BAD_ARG = -1,        /* null pointer / non-positive dimension             */
+  SRK_ERR_UNSUPPORTED = -2,    /* combination of modes not implemented              */
+  SRK_ERR_ALIGNMENT = -3,      /* view not 16-byte aligned where a vector path needs */
+  SRK_ERR_WORKSPACE = -4,      /* workspace too small                                */
+  SRK_ERR_LAUNCH = -5          /* hipLaunchKernel reported an error                 */
+} srk_status;
+
+/* how the logical conv input is read from memory */
+typedef enum srk_in_mode {
+  SRK_IN_PLAIN = 0,
+  SRK_IN_UNSHUFFLE = 1, /* logical (h,w,k*Cps+c), k=2i+j  <-  mem (2h+i, 2w+j, c): the inverse of
+                           nn.PixelShuffle(2) (models.py:89) folded into the load (backward of the
+                           upsampling conv) */
+  SRK_IN_ZERO_UPSAMPLE = 2 /* logical (uh,uw) = mem (uh/2,uw/2) if both even else 0: data-gradient of
+                              a stride-2 conv (models.py:144) as a stride-1 conv */
+} srk_in_mode;
+
+/* A fused 3x3 / pad 1 convolution (forward or data-gradient):
+ *   t = sum_{r,s,c} Wp[o][r][s][c] * X[n, S*oh + r - 1, S*ow + s - 1, c]  + bias[o]
+ *   t = alpha * t + beta1 * R1[...] + beta2 * R2[...]
+ *   t = t > 0 ? t : slope * t                     (slope == 1 -> none)
+ *   t = t * (M[...] > 0 ? 1 : mask_slope)          (M == NULL -> none; LeakyReLU backward)
+ *   Y[n, oh, ow, o] = t        or, with ps_out, Y[n, 2oh+i, 2ow+j, c] for packed o = (2i+j)*Cout/4 + c
+ * R1, R2, M are read at the same physical (pixel, channel) as the Y store, through their own ldc/coff.
+ *
+ * Replaces: nn.Conv2d(.,.,3,stride,1) + nn.LeakyReLU + torch.cat + .mul(res_scale)+x + torch.add +
+ * nn.PixelShuffle of models.py:19-21,36-41,53,63,67,86-90,97-99,126,142-145,168 and their autograd
+ * data-gradients. */
+typedef struct srk_conv_args {
+  int32_t N, H, W;          /* logical input extent (for SRK_IN_ZERO_UPSAMPLE: extent of the stored tensor) */
+  int32_t OH, OW;           /* logical output extent (before ps_out) */
+  int32_t Cin, Cout;
+  int32_t stride;           /* 1 or 2 */
+  int32_t in_mode;          /* srk_in_mode */
+  int32_t ps_out;           /* 0 | 1: PixelShuffle(2) folded into the store */
+  const float* x;  int32_t x_ldc, x_coff;
+  const float* wp;          /* packed weights, srk_pack_weights layout for (Cin, Cout) */
+  const float* bias;        /* [Cout] in packed-o order, or NULL */
+  float* y;        int32_t y_ldc, y_coff;
+  float alpha;
+  const float* r1; int32_t r1_ldc, r1_coff; float beta1;
+  const float* r2; int32_t r2_ldc, r2_coff; float beta2;
+  float slope;
+  const float* mask; int32_t m_ldc, m_coff; float mask_slope;
+} srk_conv_args;
+
+int srk_conv3x3(const srk_conv_args* a, void* stream);
+
+/* Weight-gradient of the same convolution:
+ *   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]
+ *   db[o]          = scale * sum DY[n,oh,ow,o]                       (db may be NULL)
+ * written in canonical OIHW order (accumulate == 0: overwrite, 1: add to dW/db).
+ * DY may be read through SRK_IN_UNSHUFFLE (dy_mode); then o is the packed order and the result is
+ * un-permuted on store.  Two launches: partial sums per pixel-split into `workspace`, then a
+ * deterministic (fixed-order) reduction -- no float atomics.
+ * Replaces the autograd weight/bias gradient of nn.Conv2d (models.py:19,63,67,87,97,99,142,144,168). */
+typedef struct srk_wgrad_args {
+  int32_t N, H, W;          /* x extent */
+  int32_t OH, OW;           /* dy logical extent */
+  int32_t Cin, Cout;
+  int32_t stride;
+  int32_t dy_mode;          /* SRK_IN_PLAIN | SRK_IN_UNSHUFFLE */
+  const float* x;  int32_t x_ldc, x_coff;
+  const float* dy; int32_t dy_ldc, dy_coff;
+  float* dw;                /* [Cout][Cin][3][3] */
+  float* db;                /* [Cout] or NULL */
+  float scale;
+  int32_t accumulate;
+  void* workspace; size_t workspace_bytes;
+} srk_wgrad_args;
+
+int srk_conv3x3_wgrad(const srk_wgrad_args* a, void* stream);
+int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* a, size_t* bytes);
+
+/* Weight packing (OIHW fp32 -> MFMA-fragment order).  One launch packs a whole table.
+ * Destination layout for a conv with K input channels and M outputs, Mp = round_up(M, 32):
+ *   dst[q][tap][h][m][e]  (q = K/8 chunks, tap = 3r+s, h in {0,1}, e in 0..3)
+ *       = scale * SRC(m, k = 8q + 4h + e, tap)      (0 where k >= K or m >= M)
+ * forward entry  (transpose == 0): SRC(m,k,tap) = W[m'][c_begin + k - k_off][tap]
+ * backward entry (transpose == 1): SRC(m,k,tap) = W[k' ][c_begin + m][8 - tap], k' from k - k_off
+ * where x' = ps ? 4*(x % (Cout_src/4)) + x / (Cout_src/4) : x maps packed PixelShuffle order to OIHW rows.
+ * Several entries may fill disjoint k ranges [k_off, k_off + k_len) of one dst (the backward of a
+ * DenseResidualBlock reads the concatenation of dy5..dy(j+1)). */
+typedef struct srk_pack_entry {
+  const float* src;         /* OIHW [src_cout][src_cin][3][3] */
+  float* dst;
+  int32_t src_cout, src_cin;
+  int32_t transpose;
+  int32_t c_begin;          /* first src input channel used */
+  int32_t M;                /* logical outputs of dst (fwd: src_cout; bwd: slice width) */
+  int32_t k_off, k_len;     /* dst k range filled by this entry (k_off % 8 == 0) */
+  int32_t K_total;          /* total K of dst (for zero fill of the tail chunk) */
+  int32_t ps;
+  float scale;
+  int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
+} srk_pack_entry;
+
+/* fills elem_begin for each entry, returns total work items in *total */
+int srk_pack_plan(srk_pack_entry* host_entries, int n, int64_t* total);
+/* device_entries: the same table copied to device memory by the caller */
+int srk_pack_weights(const srk_pack_entry* device_entries, int n, int64_t total, void* stream);
+size_t srk_packed_floats(int K, int M);
+
+/* Standalone nn.PixelShuffle(2) forward / backward on NHWC (models.py:89); C = channels of the
+ * shuffled tensor, x is [N,H,W,4C] in OIHW channel order (c*4 + 2i + j), y is [N,2H,2W,C]. */
+int srk_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int srk_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* NCHW <-> NHWC view copies (boundary tensors are NCHW, esrgan.py:404-405) */
+int srk_nchw_to_nhwc(const float* x, float* y, int y_ldc, int y_coff, int N, int C, int H, int W, void* stream);
+int srk_nhwc_to_nchw(const float* x, int x_ldc, int x_coff, float* y, int N, int C, int H, int W, void* stream);
+
+/* k*k sum pooling NHWC/NCHW with C folded into N (SumPool2d, models.py:297-305) and its gradient */
+int srk_sum_pool_fwd(const float* x, float* y, int NC, int H, int W, int k, void* stream);
+int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W, int k, void* stream);
+
+const char* srk_strerror(int status);
+int srk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRK_H */

@@ -1,0 +1,296 @@
+"""CPU oracle for the ESRGAN hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU fp32 restatement of the reference's arithmetic
+for the hot path.  It is *not* part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it, and only as the checker.  The product path
+(``super-resolution_amd``) never imports anything from ``oracle/``.
+
+Parity pin: the functions here are checked against the imported reference
+(``/root/reference/models.py``) by ``tools/make_golden.py`` in the build
+container, and against the committed fixtures ``tests/golden/*.npz`` by
+``tests/test_oracle_golden.py`` everywhere else.
+
+Everything operates on a flat ``dict[str, Tensor]`` with the reference's
+``state_dict`` key names (OIHW fp32 weights), NCHW fp32 activations.
+
+Reference citations (file:line in /root/reference):
+  models.py:14-41   DenseResidualBlock        -> dense_residual_block
+  models.py:44-53   ResidualInResidualDenseBlock -> rrdb
+  models.py:56-135  GeneratorRRDB             -> generator_forward
+  models.py:140-174 Markovian_Discriminator   -> discriminator_forward
+  models.py:297-305 SumPool2d                 -> sum_pool
+  esrgan.py:416-439 warm-up step              -> warmup_step
+  esrgan.py:457-555 G phase                   -> g_phase_loss
+  esrgan.py:561-626 D phase                   -> d_phase_loss
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+G_SLOPE = 0.01   # nn.LeakyReLU() default, models.py:21,75,88,98
+D_SLOPE = 0.2    # nn.LeakyReLU(0.2), models.py:143,145
+INNER_RES_SCALE = 0.2  # DenseResidualBlock default; RRDB does not forward its arg (models.py:49)
+
+
+# --------------------------------------------------------------------------- utils
+def closed_form_fill(sd: Dict[str, Tensor], gain: float = 1.0) -> Dict[str, Tensor]:
+    """Deterministic, storage-free weights: for the li-th key (sorted order) element i
+    of a conv weight is ``gain/sqrt(fan_in) * sin(0.37*i + li)``; biases
+    ``0.05*sin(0.91*i + li)``.  ``power``/``multiplier`` are left untouched."""
+    out = {}
+    for li, k in enumerate(sorted(sd.keys())):
+        t = sd[k]
+        if k in ("power", "multiplier"):
+            out[k] = t.clone()
+            continue
+        n = t.numel()
+        idx = torch.arange(n, dtype=torch.float64)
+        if t.dim() == 4:
+            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+            v = gain / math.sqrt(fan_in) * torch.sin(0.37 * idx + li)
+        else:
+            v = 0.05 * torch.sin(0.91 * idx + li)
+        out[k] = v.to(torch.float32).reshape(t.shape)
+    return out
+
+
+def jet_images(n: int, c: int, h: int, w: int, seed: int, factor: int):
+    """Synthetic jet-like sparse non-negative HR images and their LR sum-pool
+    (LR construction = datasets.py:227,247 SumPool2d)."""
+    g = torch.Generator().manual_seed(seed)
+    hr = 10.0 * torch.rand(n, c, h, w, generator=g) * (torch.rand(n, c, h, w, generator=g) < 0.1).float()
+    lr = sum_pool(hr, factor)
+    return lr, hr
+
+
+def lrelu(x: Tensor, slope: float) -> Tensor:
+    return torch.where(x > 0, x, x * slope)
+
+
+def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int = 1) -> Tensor:
+    """nn.Conv2d(kernel_size=3, stride, padding=1) (models.py:19,63,67,87,97,99,142,144,168)."""
+    return F.conv2d(x, w, b, stride=stride, padding=1)
+
+
+def pixel_shuffle(x: Tensor, r: int = 2) -> Tensor:
+    """nn.PixelShuffle(r) (models.py:89): out[n,c,r*h+i,r*w+j] = in[n,c*r*r+r*i+j,h,w]."""
+    n, c, h, w = x.shape
+    co = c // (r * r)
+    x = x.reshape(n, co, r, r, h, w)
+    x = x.permute(0, 1, 4, 2, 5, 3)
+    return x.reshape(n, co, h * r, w * r)
+
+
+def sum_pool(x: Tensor, k: int) -> Tensor:
+    """SumPool2d (models.py:297-305): k*k * AvgPool2d(k)."""
+    return (k * k) * F.avg_pool2d(x, k)
+
+
+# --------------------------------------------------------------------------- generator
+def dense_residual_block(sd, prefix: str, x: Tensor) -> Tensor:
+    """models.py:34-41 (drop_rate=0)."""
+    inputs = x
+    out = x
+    for k in range(1, 6):
+        out = conv3x3(inputs, sd[f"{prefix}.b{k}.0.weight"], sd[f"{prefix}.b{k}.0.bias"])
+        if k < 5:
+            out = lrelu(out, G_SLOPE)
+        inputs = torch.cat([inputs, out], 1)
+    return out * INNER_RES_SCALE + x
+
+
+def rrdb(sd, prefix: str, x: Tensor, res_scale: float) -> Tensor:
+    """models.py:52-53."""
+    out = x
+    for j in range(3):
+        out = dense_residual_block(sd, f"{prefix}.dense_blocks.{j}", out)
+    return out * res_scale + x
+
+
+def _out(x: Tensor, thres: float, pw: float, training: bool) -> Tensor:
+    """GeneratorRRDB.out, models.py:114-118."""
+    lambd = float(thres) ** float(pw)
+    if training:
+        return F.hardshrink(x, lambd=lambd)
+    return F.hardshrink(F.relu(x), lambd=lambd)
+
+
+def generator_forward(sd, x: Tensor, num_res_blocks: int, num_upsample: int,
+                      res_scale: float = 0.2, training: bool = True, thres: float = 0.0,
+                      num_final_layer_res: int = 0) -> Tuple[Tensor, Tensor]:
+    """GeneratorRRDB.forward, models.py:120-135 (default upsampling branch 84-90).
+    Returns (output, srs)."""
+    power = sd["power"]
+    mult = sd["multiplier"]
+    x = mult * (x ** power)
+    out1 = conv3x3(x, sd["conv1.weight"], sd["conv1.bias"])
+    out = out1
+    for i in range(num_res_blocks):
+        out = rrdb(sd, f"res_blocks.{i}", out, res_scale)
+    out2 = conv3x3(out, sd["conv2.weight"], sd["conv2.bias"])
+    out = out1 + out2
+    for u in range(num_upsample):
+        out = conv3x3(out, sd[f"upsampling.{3*u}.weight"], sd[f"upsampling.{3*u}.bias"])
+        out = lrelu(out, G_SLOPE)
+        out = pixel_shuffle(out, 2)
+    if num_final_layer_res > 0:
+        o3 = out
+        for i in range(num_final_layer_res):
+            o3 = rrdb(sd, f"res_blocks_final.{i}", o3, res_scale)
+        out = o3 + out
+    out = conv3x3(out, sd["conv3.0.weight"], sd["conv3.0.bias"])
+    out = lrelu(out, G_SLOPE)
+    out = conv3x3(out, sd["conv3.2.weight"], sd["conv3.2.bias"]) / mult
+    srs = _out(out, thres, float(power), training)
+    if float(power) != 1:
+        out = F.relu(out) ** (1 / power)
+    return _out(out, thres, 1.0, training), srs
+
+
+def generator_state_shapes(channels=1, filters=64, num_res_blocks=10, num_upsample=1,
+                           num_final_layer_res=0) -> Dict[str, Tuple[int, ...]]:
+    """state_dict key -> shape for GeneratorRRDB (models.py:58-106)."""
+    F_ = filters
+    sh = {"power": (1,), "multiplier": (1,),
+          "conv1.weight": (F_, channels, 3, 3), "conv1.bias": (F_,),
+          "conv2.weight": (F_, F_, 3, 3), "conv2.bias": (F_,)}
+
+    def add_rrdbs(name, n):
+        for i in range(n):
+            for j in range(3):
+                for k in range(1, 6):
+                    p = f"{name}.{i}.dense_blocks.{j}.b{k}.0"
+                    sh[p + ".weight"] = (F_, k * F_, 3, 3)
+                    sh[p + ".bias"] = (F_,)
+    add_rrdbs("res_blocks", num_res_blocks)
+    for u in range(num_upsample):
+        sh[f"upsampling.{3*u}.weight"] = (4 * F_, F_, 3, 3)
+        sh[f"upsampling.{3*u}.bias"] = (4 * F_,)
+    add_rrdbs("res_blocks_final", num_final_layer_res)
+    sh["conv3.0.weight"] = (F_, F_, 3, 3)
+    sh["conv3.0.bias"] = (F_,)
+    sh["conv3.2.weight"] = (channels, F_, 3, 3)
+    sh["conv3.2.bias"] = (channels,)
+    return sh
+
+
+def default_init_generator(seed: int, **cfg) -> Dict[str, Tensor]:
+    """PyTorch default Conv2d init (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)),
+    bias U(+-1/sqrt(fan_in))) in state-dict key order, own RNG stream."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    shapes = generator_state_shapes(**cfg)
+    for k, s in shapes.items():
+        if k == "power" or k == "multiplier":
+            sd[k] = torch.ones(1)
+        elif k.endswith("weight"):
+            bound = 1.0 / math.sqrt(s[1] * 9)
+            sd[k] = (torch.rand(s, generator=g) * 2 - 1) * bound
+        else:
+            wk = k[:-4] + "weight"
+            bound = 1.0 / math.sqrt(shapes[wk][1] * 9)
+            sd[k] = (torch.rand(s, generator=g) * 2 - 1) * bound
+    return sd
+
+
+# --------------------------------------------------------------------------- discriminator
+def discriminator_state_shapes(in_channels=1, channels=(16, 32, 32, 64)):
+    """Markovian_Discriminator (models.py:149-171): model.{0,2,...}."""
+    sh = {}
+    idx = 0
+    cin = in_channels
+    for co in channels:
+        sh[f"model.{idx}.weight"] = (co, cin, 3, 3); sh[f"model.{idx}.bias"] = (co,)
+        sh[f"model.{idx+2}.weight"] = (co, co, 3, 3); sh[f"model.{idx+2}.bias"] = (co,)
+        idx += 4
+        cin = co
+    sh[f"model.{idx}.weight"] = (1, cin, 3, 3); sh[f"model.{idx}.bias"] = (1,)
+    return sh
+
+
+def discriminator_output_shape(input_shape, channels=(16, 32, 32, 64)):
+    """models.py:156-170: ceil(H/2) per block."""
+    _, h, w = input_shape
+    for _ in channels:
+        h = int(math.ceil(h / 2)); w = int(math.ceil(w / 2))
+    return (1, h, w)
+
+
+def discriminator_forward(sd, img: Tensor, channels=(16, 32, 32, 64)) -> Tensor:
+    """Markovian_Discriminator.forward (models.py:173-174) over discriminator_block (140-146)."""
+    x = img
+    idx = 0
+    for _ in channels:
+        x = lrelu(conv3x3(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], 1), D_SLOPE)
+        x = lrelu(conv3x3(x, sd[f"model.{idx+2}.weight"], sd[f"model.{idx+2}.bias"], 2), D_SLOPE)
+        idx += 4
+    return conv3x3(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], 1)
+
+
+# --------------------------------------------------------------------------- train-step losses
+EPS = 1e-7  # esrgan.py:319
+
+
+def bce_logits(x: Tensor, target: Tensor) -> Tensor:
+    return F.binary_cross_entropy_with_logits(x, target)
+
+
+def warmup_loss(gen_hr: Tensor, hr: Tensor) -> Tensor:
+    """esrgan.py:424: L1(G(lr), hr)."""
+    return (gen_hr - hr).abs().mean()
+
+
+def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Sequence[dict],
+                 factor: int, scaling_power: float = 1.0, lambdas=(0.2, 1.0),
+                 lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1,
+                 d_channels=(16, 32, 32, 64)):
+    """esrgan.py:468-552 at default flags (relativistic, hr+lr+adv terms only).
+    ``generated`` = [G(lr), G.srs].  Returns (loss_G, dict of parts)."""
+    ground_truth = [hr, hr ** scaling_power]
+    gen_lr = sum_pool(generated[0], factor)
+    generated_lr = [gen_lr, gen_lr ** scaling_power]
+    ground_truth_lr = [lr, lr ** scaling_power]
+    loss_G = torch.zeros(1)
+    parts = {}
+    for k in range(2):
+        if lambdas[k] <= 0:
+            continue
+        loss_pixel = (generated[k].mean(0)[None] - ground_truth[k].mean(0)[None]).abs().mean()
+        loss_lr = (generated_lr[k] - ground_truth_lr[k]).abs().mean()
+        pred_real = discriminator_forward(d_sds[k], ground_truth[k], d_channels).detach()
+        pred_fake = discriminator_forward(d_sds[k], generated[k], d_channels)
+        valid = torch.ones_like(pred_real)
+        fake = torch.zeros_like(pred_real)
+        loss_gan = 0.5 * (bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), valid) +
+                          bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), fake))
+        tot = lambda_hr * loss_pixel + lambda_adv * loss_gan + lambda_lr * loss_lr
+        loss_G = loss_G + lambdas[k] * tot
+        parts[k] = dict(pixel=loss_pixel, lr=loss_lr, adv=loss_gan, tot=tot)
+    return loss_G, parts
+
+
+def d_phase_loss(d_sd: dict, gt: Tensor, gen_detached: Tensor, epsilon: Optional[Tensor],
+                 lambda_reg=0.01, d_channels=(16, 32, 32, 64)):
+    """esrgan.py:569-606 for one discriminator (relativistic + gradient penalty).
+    ``epsilon``: (B,1,1,1) interpolation factors (esrgan.py:598) or None to skip GP."""
+    pred_real = discriminator_forward(d_sd, gt, d_channels)
+    pred_fake = discriminator_forward(d_sd, gen_detached, d_channels)
+    valid = torch.ones_like(pred_real)
+    fake = torch.zeros_like(pred_real)
+    loss_real = bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), valid)
+    loss_fake = bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), fake)
+    loss_D = (loss_real + loss_fake) / 2
+    gp = None
+    if lambda_reg > 0 and epsilon is not None:
+        interp = (epsilon * gt + (1 - epsilon) * gen_detached).detach().requires_grad_(True)
+        pred_i = discriminator_forward(d_sd, interp, d_channels)
+        grads = torch.autograd.grad(pred_i, interp, grad_outputs=valid, create_graph=True,
+                                    retain_graph=True, only_inputs=True)[0]
+        grads = grads.view(gt.shape[0], -1)
+        gp = ((grads.norm(2, dim=1) - 1) ** 2).mean() * lambda_reg / 2
+        loss_D = loss_D + gp
+    return loss_D, gp

@@ -1,0 +1,224 @@
+"""ctypes binding of the C-ABI library ``libsrk.so`` (include/srk.h).
+
+The binding is deliberately thin: it converts tensors to raw device pointers, fills the plain-C
+argument structs and turns a non-zero ``srk_status`` into ``RuntimeError``.  It never falls back to
+another implementation: if the library is missing the import of the compute path fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrk.so")
+
+IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
+
+EXPORTS = [
+    "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_pack_plan", "srk_pack_weights",
+    "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
+    "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_strerror", "srk_version",
+]
+
+_fp = C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32), ("in_mode", C.c_int32), ("ps_out", C.c_int32),
+        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32),
+        ("wp", _fp), ("bias", _fp),
+        ("y", _fp), ("y_ldc", C.c_int32), ("y_coff", C.c_int32),
+        ("alpha", C.c_float),
+        ("r1", _fp), ("r1_ldc", C.c_int32), ("r1_coff", C.c_int32), ("beta1", C.c_float),
+        ("r2", _fp), ("r2_ldc", C.c_int32), ("r2_coff", C.c_int32), ("beta2", C.c_float),
+        ("slope", C.c_float),
+        ("mask", _fp), ("m_ldc", C.c_int32), ("m_coff", C.c_int32), ("mask_slope", C.c_float),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32), ("dy_mode", C.c_int32),
+        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32),
+        ("dy", _fp), ("dy_ldc", C.c_int32), ("dy_coff", C.c_int32),
+        ("dw", _fp), ("db", _fp), ("scale", C.c_float), ("accumulate", C.c_int32),
+        ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [
+        ("src", _fp), ("dst", _fp), ("src_cout", C.c_int32), ("src_cin", C.c_int32), ("transpose", C.c_int32),
+        ("c_begin", C.c_int32), ("M", C.c_int32), ("k_off", C.c_int32), ("k_len", C.c_int32), ("K_total", C.c_int32),
+        ("ps", C.c_int32), ("scale", C.c_float), ("elem_begin", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsrk.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C super-resolution_amd/csrc`). There is no CPU/PyTorch fallback for the hot path.")
+        L = C.CDLL(LIB_PATH)
+        L.srk_strerror.restype = C.c_char_p
+        L.srk_strerror.argtypes = [C.c_int]
+        L.srk_version.restype = C.c_int
+        L.srk_packed_floats.restype = C.c_size_t
+        L.srk_packed_floats.argtypes = [C.c_int, C.c_int]
+        L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
+        L.srk_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), _fp]
+        L.srk_conv3x3_wgrad_workspace.argtypes = [C.POINTER(WgradArgs), C.POINTER(C.c_size_t)]
+        L.srk_pack_plan.argtypes = [C.POINTER(PackEntry), C.c_int, C.POINTER(C.c_int64)]
+        L.srk_pack_weights.argtypes = [_fp, C.c_int, C.c_int64, _fp]
+        for name in ("srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd"):
+            getattr(L, name).argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.srk_nchw_to_nhwc.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.srk_nhwc_to_nchw.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        for name in ("srk_sum_pool_fwd", "srk_sum_pool_bwd"):
+            getattr(L, name).argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {lib().srk_strerror(status).decode()} (status {status})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class View:
+    """An NHWC channel-slice view ``base[pixel*ldc + coff + c]`` of a contiguous [N,H,W,ldc] fp32 tensor."""
+    __slots__ = ("t", "ldc", "coff", "C")
+
+    def __init__(self, t: torch.Tensor, coff: int = 0, C_: int = None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4, "NHWC fp32 contiguous CUDA tensor expected"
+        self.t = t
+        self.ldc = t.shape[3]
+        self.coff = coff
+        self.C = (self.ldc - coff) if C_ is None else C_
+        assert 0 <= coff and coff + self.C <= self.ldc
+
+
+def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
+            ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
+            mask: View = None, mask_slope=1.0):
+    a = ConvArgs()
+    a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout = N, H, W, OH, OW, Cin, Cout
+    a.stride, a.in_mode, a.ps_out = stride, in_mode, int(ps_out)
+    a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
+    a.wp, a.bias = wp.data_ptr(), ptr(bias)
+    a.y, a.y_ldc, a.y_coff = y.t.data_ptr(), y.ldc, y.coff
+    a.alpha = alpha
+    if r1 is not None:
+        a.r1, a.r1_ldc, a.r1_coff, a.beta1 = r1.t.data_ptr(), r1.ldc, r1.coff, beta1
+    if r2 is not None:
+        a.r2, a.r2_ldc, a.r2_coff, a.beta2 = r2.t.data_ptr(), r2.ldc, r2.coff, beta2
+    a.slope = slope
+    if mask is not None:
+        a.mask, a.m_ldc, a.m_coff, a.mask_slope = mask.t.data_ptr(), mask.ldc, mask.coff, mask_slope
+    check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
+                  scale=1.0, accumulate=False):
+    a = WgradArgs()
+    a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout, a.stride, a.dy_mode = N, H, W, OH, OW, Cin, Cout, stride, dy_mode
+    a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
+    a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff
+    a.dw, a.db, a.scale, a.accumulate = dw.data_ptr(), ptr(db), scale, int(accumulate)
+    nbytes = C.c_size_t(0)
+    check(lib().srk_conv3x3_wgrad_workspace(C.byref(a), C.byref(nbytes)), "srk_conv3x3_wgrad_workspace")
+    ws = _workspace(nbytes.value, x.t.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
+
+
+def packed_floats(K: int, M: int) -> int:
+    return lib().srk_packed_floats(K, M)
+
+
+class PackTable:
+    """A batch of weight-packing jobs executed by ONE kernel launch (srk_pack_weights)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = []
+        self._dev = None
+        self._total = 0
+
+    def add(self, src: torch.Tensor, dst: torch.Tensor, *, M, k_off, k_len, K_total, transpose=False, c_begin=0, ps=False, scale=1.0):
+        assert src.dim() == 4 and src.shape[2] == 3 and src.shape[3] == 3 and src.is_contiguous()
+        e = PackEntry()
+        e.src, e.dst = src.data_ptr(), dst.data_ptr()
+        e.src_cout, e.src_cin = src.shape[0], src.shape[1]
+        e.transpose, e.c_begin, e.M, e.k_off, e.k_len, e.K_total = int(transpose), c_begin, M, k_off, k_len, K_total
+        e.ps, e.scale = int(ps), scale
+        self.entries.append(e)
+        self._dev = None
+
+    def finalize(self):
+        n = len(self.entries)
+        arr = (PackEntry * n)(*self.entries)
+        total = C.c_int64(0)
+        check(lib().srk_pack_plan(arr, n, C.byref(total)), "srk_pack_plan")
+        self._total = total.value
+        raw = bytes(arr)
+        self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._n = n
+
+    def run(self):
+        if self._dev is None:
+            self.finalize()
+        check(lib().srk_pack_weights(self._dev.data_ptr(), self._n, self._total, stream_ptr()), "srk_pack_weights")
+
+
+def pixel_shuffle_fwd(x, y, N, H, W, C_):
+    check(lib().srk_pixel_shuffle_fwd(x.data_ptr(), y.data_ptr(), N, H, W, C_, stream_ptr()), "srk_pixel_shuffle_fwd")
+
+
+def pixel_shuffle_bwd(dy, dx, N, H, W, C_):
+    check(lib().srk_pixel_shuffle_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W, C_, stream_ptr()), "srk_pixel_shuffle_bwd")
+
+
+def nchw_to_nhwc(x, y: View, N, C_, H, W):
+    check(lib().srk_nchw_to_nhwc(x.data_ptr(), y.t.data_ptr(), y.ldc, y.coff, N, C_, H, W, stream_ptr()), "srk_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x: View, y, N, C_, H, W):
+    check(lib().srk_nhwc_to_nchw(x.t.data_ptr(), x.ldc, x.coff, y.data_ptr(), N, C_, H, W, stream_ptr()), "srk_nhwc_to_nchw")
+
+
+def sum_pool_fwd(x, y, NC, H, W, k):
+    check(lib().srk_sum_pool_fwd(x.data_ptr(), y.data_ptr(), NC, H, W, k, stream_ptr()), "srk_sum_pool_fwd")
+
+
+def sum_pool_bwd(dy, dx, NC, H, W, k):
+    check(lib().srk_sum_pool_bwd(dy.data_ptr(), dx.data_ptr(), NC, H, W, k, stream_ptr()), "srk_sum_pool_bwd")

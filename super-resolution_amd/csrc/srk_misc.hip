@@ -1,0 +1,219 @@
+// srk_misc.hip -- bandwidth-bound helpers for gfx950: weight packing, standalone PixelShuffle,
+// NCHW<->NHWC boundary copies, SumPool2d.  All are one-pass, coalesced on the side that matters.
+#include "srk_internal.h"
+#include <string.h>
+
+namespace {
+
+// ---------------------------------------------------------------- weight packing
+// work item = one float4 of dst: (q_local, tap, h, m) -> 4 consecutive k.
+__global__ void pack_kernel(const srk_pack_entry* __restrict__ tab, int n, long total) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  // binary search entry with elem_begin <= gid
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].elem_begin <= gid) lo = mid; else hi = mid - 1;
+  }
+  const srk_pack_entry e = tab[lo];
+  long t = gid - e.elem_begin;
+  const int Mp = (e.M + 31) & ~31;
+  const int m = (int)(t % Mp); t /= Mp;
+  const int h = (int)(t & 1); t >>= 1;
+  const int tap = (int)(t % 9); t /= 9;
+  const int ql = (int)t;                      // chunk index relative to k_off/8
+  const int q = (e.k_off >> 3) + ql;
+  const int Cps = e.src_cout >> 2;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 8 * q + 4 * h + j;          // dst k
+    const int kr = k - e.k_off;               // k relative to this entry
+    float val = 0.f;
+    if (m < e.M && kr >= 0 && kr < e.k_len) {
+      if (!e.transpose) {
+        int o = m;
+        if (e.ps) o = 4 * (m % Cps) + m / Cps;
+        val = e.src[((long)o * e.src_cin + e.c_begin + kr) * 9 + tap];
+      } else {
+        int o = kr;
+        if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
+        val = e.src[((long)o * e.src_cin + e.c_begin + m) * 9 + (8 - tap)];
+      }
+      val *= e.scale;
+    }
+    v[j] = val;
+  }
+  float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * 9 + tap) * 2 + h) * Mp + m;
+  *d = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---------------------------------------------------------------- pixel shuffle (standalone)
+// x [N,H,W,4C] (channel = 4c + 2i + j)  ->  y [N,2H,2W,C]; one thread per output float4
+__global__ void pixel_shuffle_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const long total = (long)N * 2 * H * 2 * W * C;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;
+    const int c = (int)(t % C); t /= C;
+    const int ow = (int)(t % (2 * W)); t /= (2 * W);
+    const int oh = (int)(t % (2 * H)); t /= (2 * H);
+    const int n = (int)t;
+    const int h = oh >> 1, i = oh & 1, w = ow >> 1, j = ow & 1;
+    y[gid] = x[(((long)n * H + h) * W + w) * (4 * C) + 4 * c + 2 * i + j];
+  }
+}
+__global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+  const long total = (long)N * H * W * 4 * C;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;
+    const int ch = (int)(t % (4 * C)); t /= (4 * C);
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int n = (int)t;
+    const int c = ch >> 2, i = (ch >> 1) & 1, j = ch & 1;
+    dx[gid] = dy[(((long)n * 2 * H + 2 * h + i) * (2 * W) + 2 * w + j) * C + c];
+  }
+}
+
+// ---------------------------------------------------------------- layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int ldc, int coff, int N, int C, int H, int W) {
+  const long total = (long)N * C * H * W;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;   // iterate in NHWC order of the destination
+    const int c = (int)(t % C); t /= C;
+    const long pix = t % ((long)H * W); t /= ((long)H * W);
+    const int n = (int)t;
+    y[((long)n * H * W + pix) * ldc + coff + c] = x[((long)n * C + c) * H * W + pix];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldc, int coff, float* __restrict__ y, int N, int C, int H, int W) {
+  const long total = (long)N * C * H * W;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;   // NCHW order of the destination
+    const long pix = t % ((long)H * W); t /= ((long)H * W);
+    const int c = (int)(t % C); t /= C;
+    const int n = (int)t;
+    y[gid] = x[((long)n * H * W + pix) * ldc + coff + c];
+  }
+}
+
+// ---------------------------------------------------------------- sum pool (planes = N*C)
+__global__ void sum_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W, int k) {
+  const int OH = H / k, OW = W / k;
+  const long total = (long)NC * OH * OW;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH); t /= OH;
+    const float* p = x + ((long)t * H + oh * k) * W + ow * k;
+    float s = 0.f;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) s += p[i * W + j];
+    // k*k * avg_pool (models.py:305): avg = s / (k*k), times k*k
+    y[gid] = (float)(k * k) * (s / (float)(k * k));
+  }
+}
+__global__ void sum_pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int H, int W, int k) {
+  const int OH = H / k, OW = W / k;
+  const long total = (long)NC * H * W;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    long t = gid;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int oh = h / k, ow = w / k;
+    dx[gid] = (oh < OH && ow < OW) ? dy[((long)t * OH + oh) * OW + ow] : 0.f;
+  }
+}
+
+inline unsigned grid_for(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" size_t srk_packed_floats(int K, int M) {
+  return (size_t)srk_div_up(K, 8) * 9 * 2 * srk_round_up(M, 32) * 4;
+}
+
+extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
+  if (!e || !total || n <= 0) return SRK_ERR_BAD_ARG;
+  int64_t acc = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
+    if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
+    e[i].elem_begin = acc;
+    // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
+    int k_end = e[i].k_off + e[i].k_len;
+    int nq = srk_div_up(k_end, 8) - (e[i].k_off >> 3);
+    acc += (int64_t)nq * 9 * 2 * srk_round_up(e[i].M, 32);
+  }
+  *total = acc;
+  return SRK_OK;
+}
+
+extern "C" int srk_pack_weights(const srk_pack_entry* dev, int n, int64_t total, void* stream) {
+  if (!dev || n <= 0 || total <= 0) return SRK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dev, n, (long)total);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
+extern "C" int srk_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SRK_ERR_BAD_ARG;
+  const long total = (long)N * H * W * 4 * C;
+  hipLaunchKernelGGL(pixel_shuffle_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SRK_ERR_BAD_ARG;
+  const long total = (long)N * H * W * 4 * C;
+  hipLaunchKernelGGL(pixel_shuffle_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_nchw_to_nhwc(const float* x, float* y, int y_ldc, int y_coff, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || y_ldc < C) return SRK_ERR_BAD_ARG;
+  const long total = (long)N * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, y_ldc, y_coff, N, C, H, W);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_nhwc_to_nchw(const float* x, int x_ldc, int x_coff, float* y, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || x_ldc < C) return SRK_ERR_BAD_ARG;
+  const long total = (long)N * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, x_ldc, x_coff, y, N, C, H, W);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_sum_pool_fwd(const float* x, float* y, int NC, int H, int W, int k, void* stream) {
+  if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || k <= 0 || H < k || W < k) return SRK_ERR_BAD_ARG;
+  const long total = (long)NC * (H / k) * (W / k);
+  hipLaunchKernelGGL(sum_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, k);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W, int k, void* stream) {
+  if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || k <= 0 || H < k || W < k) return SRK_ERR_BAD_ARG;
+  const long total = (long)NC * H * W;
+  hipLaunchKernelGGL(sum_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, NC, H, W, k);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
+extern "C" const char* srk_strerror(int s) {
+  switch (s) {
+    case SRK_OK: return "ok";
+    case SRK_ERR_BAD_ARG: return "bad argument (null pointer or non-positive dimension)";
+    case SRK_ERR_UNSUPPORTED: return "unsupported mode combination";
+    case SRK_ERR_ALIGNMENT: return "view is not 16-byte aligned for the vector path";
+    case SRK_ERR_WORKSPACE: return "workspace missing or too small";
+    case SRK_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown srk status";
+  }
+}
+extern "C" int srk_version(void) { return SRK_VERSION; }

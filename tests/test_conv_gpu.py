@@ -1,0 +1,234 @@
+"""GPU parity of the raw C-ABI kernels (libsrk.so) against the CPU oracle.  Tolerance: 1e-4 relative to
+the output's max-abs for a single conv (fp32 MFMA is an fp32 fma chain; only summation order differs),
+well inside BASELINE.json's 1e-3; PixelShuffle indexing is bit-exact on integer data."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import esrgan_oracle as O  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.fixture(scope="module")
+def U():
+    import srk_testutil
+    return srk_testutil
+
+
+@pytest.mark.parametrize("ci,co,h,w,n", [
+    (1, 64, 8, 8, 2), (3, 16, 9, 7, 1), (8, 32, 16, 16, 1), (16, 16, 20, 33, 2), (64, 64, 64, 64, 2),
+    (320, 64, 16, 16, 1), (64, 256, 8, 24, 1), (64, 1, 33, 17, 1), (12, 40, 10, 10, 1), (64, 96, 8, 16, 1)])
+def test_conv_fwd_plain(U, ci, co, h, w, n):
+    L = U.L
+    x = _rand((n, ci, h, w), 1)
+    wt = _rand((co, ci, 3, 3), 2, 1.0 / np.sqrt(9 * ci))
+    b = _rand((co,), 3, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b), 0.01)
+    xd = U.nhwc(x)
+    wp, _ = U.pack_fwd(wt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda")
+    L.conv3x3(L.View(xd), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01)
+    assert U.rel_err(U.nchw(y), ref) < TOL
+
+
+def test_conv_slices_residuals_mask(U):
+    """concat-free dense-block addressing: read a channel prefix, write a channel slice, two residuals,
+    alpha, and the LeakyReLU-backward mask (models.py:36-41,53)."""
+    L = U.L
+    n, h, w, F_ = 2, 12, 20, 16
+    xfull = _rand((n, 5 * F_, h, w), 4)
+    wt = _rand((F_, 3 * F_, 3, 3), 5, 0.05)
+    b = _rand((F_,), 6, 0.1)
+    r1 = _rand((n, F_, h, w), 7)
+    r2 = _rand((n, F_, h, w), 8)
+    m = _rand((n, F_, h, w), 9)
+    ref = 0.2 * O.conv3x3(xfull[:, F_:4 * F_], wt, b) + 0.5 * r1 + 1.0 * r2
+    ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
+    buf = U.nhwc(xfull)                       # [n,h,w,5F]; read channels F..4F
+    out = torch.zeros(n, h, w, 2 * F_, device="cuda")
+    wp, _ = U.pack_fwd(wt)
+    L.conv3x3(L.View(buf, F_, 3 * F_), wp, b.cuda(), L.View(out, F_, F_), N=n, H=h, W=w, OH=h, OW=w, Cin=3 * F_, Cout=F_,
+              alpha=0.2, r1=L.View(U.nhwc(r1)), beta1=0.5, r2=L.View(U.nhwc(r2, ldc=24, coff=8), 8, F_), beta2=1.0,
+              mask=L.View(U.nhwc(m)), mask_slope=0.01)
+    assert U.rel_err(U.nchw(out, F_, F_), ref) < TOL
+    assert out[..., :F_].abs().max().item() == 0.0      # neighbours of the slice untouched
+
+
+@pytest.mark.parametrize("F_", [8, 16, 64])
+def test_conv_pixel_shuffle_store(U, F_):
+    """conv F->4F + LeakyReLU + PixelShuffle(2) fused (models.py:86-90)."""
+    L = U.L
+    n, h, w = 2, 9, 13
+    x = _rand((n, F_, h, w), 10)
+    wt = _rand((4 * F_, F_, 3, 3), 11, 0.08)
+    b = _rand((4 * F_,), 12, 0.1)
+    ref = O.pixel_shuffle(O.lrelu(O.conv3x3(x, wt, b), 0.01), 2)
+    wp, _ = U.pack_fwd(wt, ps=True)
+    # bias in packed order: packed o' = ij*F + c  <->  OIHW o = 4c + ij
+    bp = b.view(F_, 4).t().contiguous().view(-1).cuda()
+    y = torch.full((n, 2 * h, 2 * w, F_), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(x)), wp, bp, L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, ps_out=True, slope=0.01)
+    assert U.rel_err(U.nchw(y), ref) < TOL
+
+
+def test_pixel_shuffle_standalone_bit_exact(U, golden_dir):
+    L = U.L
+    d = np.load(os.path.join(golden_dir, "G1_pixel_shuffle.npz"))
+    x = torch.from_numpy(d["x"]); yref = torch.from_numpy(d["y"])
+    n, c4, h, w = x.shape
+    xd = U.nhwc(x)
+    y = torch.empty(n, 2 * h, 2 * w, c4 // 4, device="cuda")
+    L.pixel_shuffle_fwd(xd, y, n, h, w, c4 // 4)
+    assert torch.equal(U.nchw(y), yref)
+    back = torch.empty_like(xd)
+    L.pixel_shuffle_bwd(y, back, n, h, w, c4 // 4)
+    assert torch.equal(back.cpu(), xd.cpu())
+
+
+@pytest.mark.parametrize("ci,co,h,w", [(1, 16, 32, 32), (16, 16, 32, 32), (32, 32, 17, 23), (64, 64, 16, 16), (16, 32, 75, 75)])
+def test_conv_stride2(U, ci, co, h, w):
+    """discriminator_block's stride-2 conv + LeakyReLU(0.2) (models.py:144-145)."""
+    L = U.L
+    n = 2
+    x = _rand((n, ci, h, w), 13)
+    wt = _rand((co, ci, 3, 3), 14, 1.0 / np.sqrt(9 * ci))
+    b = _rand((co,), 15, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b, stride=2), 0.2)
+    oh, ow = ref.shape[2:]
+    wp, _ = U.pack_fwd(wt)
+    y = torch.full((n, oh, ow, co), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(x)), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=oh, OW=ow, Cin=ci, Cout=co, stride=2, slope=0.2)
+    assert U.rel_err(U.nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("ci,co,h,w,stride", [(64, 64, 16, 16, 1), (192, 64, 10, 18, 1), (1, 16, 16, 16, 1), (16, 16, 32, 32, 2),
+                                                (32, 32, 17, 23, 2), (64, 1, 9, 9, 1), (3, 64, 8, 8, 1)])
+def test_conv_dgrad(U, ci, co, h, w, stride):
+    """data-gradient = the same kernel on transposed+flipped packed weights; stride 2 through zero-upsampling."""
+    L = U.L
+    n = 2
+    x = _rand((n, ci, h, w), 16).requires_grad_(True)
+    wt = _rand((co, ci, 3, 3), 17, 1.0 / np.sqrt(9 * ci))
+    y = O.conv3x3(x, wt, None, stride=stride)
+    dy = _rand(y.shape, 18)
+    y.backward(dy)
+    oh, ow = y.shape[2:]
+    wpb, _ = U.pack_bwd(wt)
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    if stride == 1:
+        L.conv3x3(L.View(U.nhwc(dy)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=co, Cout=ci)
+    else:
+        L.conv3x3(L.View(U.nhwc(dy)), wpb, None, L.View(dx), N=n, H=oh, W=ow, OH=h, OW=w, Cin=co, Cout=ci,
+                  in_mode=L.IN_ZERO_UPSAMPLE)
+    assert U.rel_err(U.nchw(dx), x.grad) < TOL
+
+
+def test_conv_dgrad_unshuffle(U):
+    """backward of conv->LeakyReLU->PixelShuffle: dy arrives in shuffled layout and is read through
+    SRK_IN_UNSHUFFLE with ps-permuted transposed weights."""
+    L = U.L
+    n, F_, h, w = 2, 16, 8, 12
+    x = _rand((n, F_, h, w), 19).requires_grad_(True)
+    wt = _rand((4 * F_, F_, 3, 3), 20, 0.08)
+    y = O.pixel_shuffle(O.conv3x3(x, wt, None), 2)
+    g = _rand(y.shape, 21)
+    y.backward(g)
+    wpb, _ = U.pack_bwd(wt, ps=True)
+    dx = torch.full((n, h, w, F_), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=4 * F_, Cout=F_, in_mode=L.IN_UNSHUFFLE)
+    assert U.rel_err(U.nchw(dx), x.grad) < TOL
+
+
+@pytest.mark.parametrize("ci,co,h,w,stride,n", [(64, 64, 16, 16, 1, 2), (128, 64, 12, 20, 1, 3), (1, 16, 16, 16, 1, 2),
+                                                  (16, 16, 32, 32, 2, 2), (32, 32, 17, 23, 2, 1), (64, 1, 9, 9, 1, 2),
+                                                  (320, 64, 64, 64, 1, 2), (3, 64, 8, 8, 1, 1), (64, 64, 75, 75, 2, 1)])
+def test_conv_wgrad(U, ci, co, h, w, stride, n):
+    L = U.L
+    x = _rand((n, ci, h, w), 22)
+    wt = _rand((co, ci, 3, 3), 23, 0.05).requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    y = O.conv3x3(x, wt, b, stride=stride)
+    dy = _rand(y.shape, 24)
+    y.backward(dy)
+    oh, ow = y.shape[2:]
+    dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+    db = torch.full((co,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=oh, OW=ow, Cin=ci, Cout=co, stride=stride)
+    assert U.rel_err(dw.cpu(), wt.grad) < TOL
+    assert U.rel_err(db.cpu(), b.grad) < TOL
+    # accumulate + scale
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=oh, OW=ow, Cin=ci, Cout=co, stride=stride,
+                    scale=0.5, accumulate=True)
+    assert U.rel_err(dw.cpu(), 1.5 * wt.grad) < TOL
+
+
+def test_conv_wgrad_unshuffle(U):
+    L = U.L
+    n, F_, h, w = 2, 16, 8, 12
+    x = _rand((n, F_, h, w), 25)
+    wt = _rand((4 * F_, F_, 3, 3), 26, 0.08).requires_grad_(True)
+    b = torch.zeros(4 * F_, requires_grad=True)
+    y = O.pixel_shuffle(O.conv3x3(x, wt, b), 2)
+    g = _rand(y.shape, 27)
+    y.backward(g)
+    dw = torch.full((4 * F_, F_, 3, 3), float("nan"), device="cuda")
+    db = torch.full((4 * F_,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(g)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, dy_mode=L.IN_UNSHUFFLE)
+    assert U.rel_err(dw.cpu(), wt.grad) < TOL
+    assert U.rel_err(db.cpu(), b.grad) < TOL
+
+
+def test_golden_G2(U, golden_dir):
+    """single conv + bias + LeakyReLU(0.01) vs the reference-generated fixture (models.py:19-21)."""
+    L = U.L
+    d = np.load(os.path.join(golden_dir, "G2_conv_lrelu.npz"))
+    for (ci, co) in [(1, 64), (64, 64), (320, 64), (64, 256), (64, 1)]:
+        x = torch.from_numpy(d[f"x_{ci}_{co}"]); yref = torch.from_numpy(d[f"y_{ci}_{co}"])
+        sd = O.closed_form_fill({"weight": torch.empty(co, ci, 3, 3), "bias": torch.empty(co)})
+        wp, _ = U.pack_fwd(sd["weight"])
+        n, _, h, w = x.shape
+        y = torch.empty(n, h, w, co, device="cuda")
+        L.conv3x3(L.View(U.nhwc(x)), wp, sd["bias"].cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01)
+        assert U.rel_err(U.nchw(y), yref) < TOL, (ci, co)
+
+
+def test_layout_and_sumpool(U, golden_dir):
+    L = U.L
+    x = _rand((2, 5, 6, 7), 30)
+    buf = torch.zeros(2, 6, 7, 8, device="cuda")
+    L.nchw_to_nhwc(x.cuda(), L.View(buf, 2, 5), 2, 5, 6, 7)
+    assert torch.equal(U.nchw(buf, 2, 5), x)
+    back = torch.empty(2, 5, 6, 7, device="cuda")
+    L.nhwc_to_nchw(L.View(buf, 2, 5), back, 2, 5, 6, 7)
+    assert torch.equal(back.cpu(), x)
+    d = np.load(os.path.join(golden_dir, "G9_sumpool.npz"))
+    xs = torch.from_numpy(d["x"]).cuda()
+    for k, key in ((4, "y4"), (2, "y2")):
+        y = torch.empty(2, 1, 16 // k, 16 // k, device="cuda")
+        L.sum_pool_fwd(xs, y, 2, 16, 16, k)
+        assert torch.allclose(y.cpu(), torch.from_numpy(d[key]), rtol=1e-6, atol=1e-6)
+        dx = torch.empty_like(xs)
+        L.sum_pool_bwd(y, dx, 2, 16, 16, k)
+        assert torch.allclose(dx.cpu(), F.interpolate(y.cpu(), scale_factor=k, mode="nearest"))
+
+
+def test_bad_args_report_status(U):
+    L = U.L
+    a = L.ConvArgs()
+    assert L.lib().srk_conv3x3(None, None) == -1
+    import ctypes
+    assert L.lib().srk_conv3x3(ctypes.byref(a), None) == -1
+    with pytest.raises(RuntimeError):
+        L.check(-2, "x")
