@@ -48,7 +48,7 @@ typedef enum srk_in_mode {
 } srk_in_mode;
 
 /* A fused 3x3 / pad 1 convolution (forward or data-gradient):
- *   t = sum_{r,s,c} Wp[o][r][s][c] * X[n, S*oh + r - 1, S*ow + s - 1, c]  + bias[o]
+ *   t = sum_{r,s,c} Wp[o][r][s][c] * lrelu_in(X[n, S*oh + r - 1, S*ow + s - 1, c])  + bias[o]
  *   t = alpha * t + beta1 * R1[...] + beta2 * R2[...]
  *   t = t > 0 ? t : slope * t                     (slope == 1 -> none)
  *   t = t * (M[...] > 0 ? 1 : mask_slope)          (M == NULL -> none; LeakyReLU backward)
@@ -66,6 +66,8 @@ typedef struct srk_conv_args {
   int32_t in_mode;          /* srk_in_mode */
   int32_t ps_out;           /* 0 | 1: PixelShuffle(2) folded into the store */
   const float* x;  int32_t x_ldc, x_coff;
+  float in_slope;           /* LeakyReLU applied to X while it is staged (1 = none): pre-activation chaining of
+                               the discriminator, conv(lrelu(z)) (models.py:142-145) */
   const float* wp;          /* packed weights, srk_pack_weights layout for (Cin, Cout) */
   const float* bias;        /* [Cout] in packed-o order, or NULL */
   float* y;        int32_t y_ldc, y_coff;
@@ -93,6 +95,7 @@ typedef struct srk_wgrad_args {
   int32_t stride;
   int32_t dy_mode;          /* SRK_IN_PLAIN | SRK_IN_UNSHUFFLE */
   const float* x;  int32_t x_ldc, x_coff;
+  float in_slope;           /* LeakyReLU applied to X while staged (1 = none) */
   const float* dy; int32_t dy_ldc, dy_coff;
   float* dw;                /* [Cout][Cin][3][3] */
   float* db;                /* [Cout] or NULL */

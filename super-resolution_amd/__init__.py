@@ -5,6 +5,9 @@ Import by string (the directory name carries a hyphen)::
     import importlib; sr = importlib.import_module("super-resolution_amd")
     G = sr.models.GeneratorRRDB(1, filters=64, num_res_blocks=23, num_upsample=2).cuda()
 """
-from . import _lib  # noqa: F401  (ctypes binding of libsrk.so; loads lazily, fails loudly)
+from . import _lib, ops, engine, models  # noqa: F401
+from .models import (GeneratorRRDB, Markovian_Discriminator, Standard_Discriminator, SumPool2d, DenseResidualBlock,  # noqa: F401
+                     ResidualInResidualDenseBlock, Conv3x3, discriminator_block, weight_reset, uniform_reset)
 
-__all__ = ["_lib"]
+__all__ = ["models", "ops", "engine", "_lib", "GeneratorRRDB", "Markovian_Discriminator", "Standard_Discriminator", "SumPool2d",
+           "DenseResidualBlock", "ResidualInResidualDenseBlock", "Conv3x3", "discriminator_block", "weight_reset", "uniform_reset"]

@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("Cin", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32), ("in_mode", C.c_int32), ("ps_out", C.c_int32),
-        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32),
+        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32), ("in_slope", C.c_float),
         ("wp", _fp), ("bias", _fp),
         ("y", _fp), ("y_ldc", C.c_int32), ("y_coff", C.c_int32),
         ("alpha", C.c_float),
@@ -42,7 +42,7 @@ class WgradArgs(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("Cin", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32), ("dy_mode", C.c_int32),
-        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32),
+        ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32), ("in_slope", C.c_float),
         ("dy", _fp), ("dy_ldc", C.c_int32), ("dy_coff", C.c_int32),
         ("dw", _fp), ("db", _fp), ("scale", C.c_float), ("accumulate", C.c_int32),
         ("workspace", _fp), ("workspace_bytes", C.c_size_t),
@@ -117,8 +117,9 @@ class View:
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
             ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
-            mask: View = None, mask_slope=1.0):
+            mask: View = None, mask_slope=1.0, in_slope=1.0):
     a = ConvArgs()
+    a.in_slope = in_slope
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout = N, H, W, OH, OW, Cin, Cout
     a.stride, a.in_mode, a.ps_out = stride, in_mode, int(ps_out)
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
@@ -148,8 +149,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
-                  scale=1.0, accumulate=False):
+                  scale=1.0, accumulate=False, in_slope=1.0):
     a = WgradArgs()
+    a.in_slope = in_slope
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout, a.stride, a.dy_mode = N, H, W, OH, OW, Cin, Cout, stride, dy_mode
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
     a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff

@@ -107,6 +107,10 @@ __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv
           if (c + 3 < a.Cin) v.w = p[3];
         }
       }
+      if (a.in_slope != 1.f) {
+        v.x = v.x > 0.f ? v.x : v.x * a.in_slope; v.y = v.y > 0.f ? v.y : v.y * a.in_slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.in_slope; v.w = v.w > 0.f ? v.w : v.w * a.in_slope;
+      }
       xr[u] = v;
     }
     const float4* wq = reinterpret_cast<const float4*>(a.wp) + (long)q * 18 * CoutP;

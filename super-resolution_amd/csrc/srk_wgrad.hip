@@ -123,6 +123,10 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
           if (ci + 3 < a.Cin) v.w = src[3];
         }
       }
+      if (a.in_slope != 1.f) {
+        v.x = v.x > 0.f ? v.x : v.x * a.in_slope; v.y = v.y > 0.f ? v.y : v.y * a.in_slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.in_slope; v.w = v.w > 0.f ? v.w : v.w * a.in_slope;
+      }
       reinterpret_cast<float4*>(xs)[idx] = v;
     }
     __syncthreads();

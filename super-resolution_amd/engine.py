@@ -1,0 +1,447 @@
+"""Host-side execution engine of the RRDB generator on the gfx950 kernels.
+
+The reference runs ``GeneratorRRDB.forward`` (models.py:120-135) as ~1000 ATen ops with a ``torch.cat`` per
+dense-block conv.  Here the whole generator is ONE autograd node: activations live in NHWC "dense buffers"
+([N,H,W,5F] per DenseResidualBlock; conv k reads the channel prefix [0,kF) and writes slice k, so the
+concatenation never exists), every conv is one ``srk_conv3x3`` launch with its elementwise neighbours fused,
+and the backward pass is the mirror image: a second dense buffer holds dy5..dy1 in reverse slice order, so the
+data-gradient of block input slice m is again a growing-prefix conv (no read-modify-write accumulation), with
+LeakyReLU' fused as a mask in the epilogue.
+
+Nothing here falls back to PyTorch convolutions: without libsrk.so / a GPU tensor it raises.
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import View
+
+G_SLOPE = 0.01            # nn.LeakyReLU() default slope (models.py:21,88,98)
+INNER_RES_SCALE = 0.2     # DenseResidualBlock.res_scale; RRDB never forwards its own (models.py:49)
+
+
+def _empty(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+class _Flat:
+    """Bump allocator over one flat fp32 tensor (16-byte aligned slices)."""
+
+    def __init__(self):
+        self.sizes = []
+
+    def reserve(self, n):
+        assert n % 4 == 0
+        self.sizes.append(n)
+        return len(self.sizes) - 1
+
+    def materialize(self, device):
+        total = sum(self.sizes)
+        self.buf = torch.zeros(max(total, 4), dtype=torch.float32, device=device)
+        self.slices = []
+        off = 0
+        for n in self.sizes:
+            self.slices.append(self.buf[off:off + n])
+            off += n
+
+
+class DrbPack:
+    """Packed weights of one DenseResidualBlock: forward convs k=1..5 and backward convs m=4..0."""
+
+    def __init__(self, filters):
+        self.F = filters
+        self.fwd = [None] * 6     # fwd[k] flat index, k = 1..5
+        self.bwd = [None] * 5     # bwd[m] flat index, m = 0..4
+
+
+class GeneratorEngine:
+    """Owns packed weights and runs forward/backward for one GeneratorRRDB module instance."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self._sig = None
+
+    # ------------------------------------------------------------------ parameter bookkeeping
+    def _conv_modules(self):
+        g = self.gen
+        convs = [("conv1", g.conv1)]
+        for i, rr in enumerate(g.res_blocks):
+            for j, d in enumerate(rr.dense_blocks):
+                for k in range(1, 6):
+                    convs.append((f"res_blocks.{i}.dense_blocks.{j}.b{k}", getattr(d, f"b{k}")[0]))
+        convs.append(("conv2", g.conv2))
+        for u in range(g.num_upsample):
+            convs.append((f"upsampling.{3*u}", g.upsampling[3 * u]))
+        if g.num_final_layer_res > 0:
+            for i, rr in enumerate(g.res_blocks_final):
+                for j, d in enumerate(rr.dense_blocks):
+                    for k in range(1, 6):
+                        convs.append((f"res_blocks_final.{i}.dense_blocks.{j}.b{k}", getattr(d, f"b{k}")[0]))
+        convs.append(("conv3.0", g.conv3[0]))
+        convs.append(("conv3.2", g.conv3[2]))
+        return convs
+
+    def params(self) -> List[torch.nn.Parameter]:
+        ps = []
+        for _, m in self._conv_modules():
+            ps += [m.weight, m.bias]
+        return ps
+
+    def _build_tables(self, device):
+        g = self.gen
+        F_, C_ = g.filters, g.channels
+        self.flat_f, self.flat_b = _Flat(), _Flat()
+        self.tab_f, self.tab_b = L.PackTable(device), L.PackTable(device)
+        jobs_f, jobs_b = [], []   # deferred (need materialized dst)
+
+        def simple(name, conv, ps=False, need_bwd=True):
+            co, ci = conv.weight.shape[:2]
+            fi = self.flat_f.reserve(L.packed_floats(ci, co))
+            jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=ci, ps=ps)))
+            bi = None
+            if need_bwd:
+                bi = self.flat_b.reserve(L.packed_floats(co, ci))
+                jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=co, transpose=True, ps=ps)))
+            return fi, bi
+
+        def drb(d, s5):
+            p = DrbPack(F_)
+            for k in range(1, 6):
+                w = getattr(d, f"b{k}")[0].weight
+                p.fwd[k] = self.flat_f.reserve(L.packed_floats(k * F_, F_))
+                jobs_f.append((w, p.fwd[k], dict(M=F_, k_off=0, k_len=k * F_, K_total=k * F_)))
+            for m in range(0, 5):
+                K = (5 - m) * F_
+                p.bwd[m] = self.flat_b.reserve(L.packed_floats(K, F_))
+                for k in range(5, m, -1):     # input slice (5-k) of the dy buffer carries dy_k
+                    w = getattr(d, f"b{k}")[0].weight
+                    jobs_b.append((w, p.bwd[m], dict(M=F_, k_off=(5 - k) * F_, k_len=F_, K_total=K, transpose=True,
+                                                     c_begin=m * F_, scale=(s5 if k == 5 else 1.0))))
+            p.s5 = s5
+            return p
+
+        self.idx = {}
+        self.idx["conv1"] = simple("conv1", g.conv1)
+        self.drbs = []
+        for rr in g.res_blocks:
+            self.drbs.append([drb(d, INNER_RES_SCALE * (rr.res_scale if j == 2 else 1.0)) for j, d in enumerate(rr.dense_blocks)])
+        self.idx["conv2"] = simple("conv2", g.conv2)
+        for u in range(g.num_upsample):
+            self.idx[f"up{u}"] = simple(f"up{u}", g.upsampling[3 * u], ps=True)
+        self.drbs_final = []
+        if g.num_final_layer_res > 0:
+            for rr in g.res_blocks_final:
+                self.drbs_final.append([drb(d, INNER_RES_SCALE * (rr.res_scale if j == 2 else 1.0)) for j, d in enumerate(rr.dense_blocks)])
+        self.idx["conv3.0"] = simple("conv3.0", g.conv3[0])
+        self.idx["conv3.2"] = simple("conv3.2", g.conv3[2])
+
+        self.flat_f.materialize(device)
+        self.flat_b.materialize(device)
+        for w, fi, kw in jobs_f:
+            self.tab_f.add(w.data, self.flat_f.slices[fi], **kw)
+        for w, bi, kw in jobs_b:
+            self.tab_b.add(w.data, self.flat_b.slices[bi], **kw)
+        self.tab_f.finalize()
+        self.tab_b.finalize()
+
+    def _ensure_packed(self, need_bwd: bool):
+        """(Re)pack the weights.  The canonical OIHW Parameters stay the source of truth (optimizer steps,
+        load_state_dict, weight_reset all write them); packing is one kernel launch over the whole table, so it
+        is simply redone on every forward (fwd table) / backward (bwd table) instead of tracking versions."""
+        ps = self.params()
+        dev = ps[0].device
+        sig = (dev, tuple(p.data_ptr() for p in ps))
+        if sig != self._sig:
+            self._build_tables(dev)
+            self._sig = sig
+        if need_bwd:
+            self.tab_b.run()
+            return
+        self.tab_f.run()
+        # packed-order biases of the PixelShuffle convs (o' = ij*F + c  <->  o = 4c + ij)
+        self.ps_bias = {}
+        for u in range(self.gen.num_upsample):
+            b = self.gen.upsampling[3 * u].bias.data
+            self.ps_bias[u] = b.view(-1, 4).t().contiguous().view(-1)
+
+    def wf(self, i):
+        return self.flat_f.slices[i]
+
+    def wb(self, i):
+        return self.flat_b.slices[i]
+
+    # ------------------------------------------------------------------ building blocks
+    def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float):
+        """One DenseResidualBlock on dense buffer D (slice 0 = block input).  ``outer_x`` is the RRDB input
+        for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53)."""
+        N, H, W = geo
+        F_ = pk.F
+        for k in range(1, 5):
+            L.conv3x3(View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_),
+                      N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)
+        b5 = d.b5[0].bias.data
+        if outer_x is None:
+            L.conv3x3(View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                      alpha=INNER_RES_SCALE, r1=View(D, 0, F_), beta1=1.0)
+        else:
+            L.conv3x3(View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                      alpha=INNER_RES_SCALE * rs, r1=View(D, 0, F_), beta1=rs, r2=outer_x, beta2=1.0)
+
+    def _drb_backward(self, d, pk: DrbPack, D, E, gx_out: View, geo, beta_self: float, outer_g: Optional[View], grads: Dict):
+        """Backward of one DenseResidualBlock.  E slice 0 holds the (unscaled) gradient of the block output; slices
+        1..4 receive dy4..dy1.  Writes the block-input gradient to ``gx_out``."""
+        N, H, W = geo
+        F_ = pk.F
+        for m in range(4, 0, -1):
+            K = (5 - m) * F_
+            L.conv3x3(View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_,
+                      mask=View(D, m * F_, F_), mask_slope=G_SLOPE)
+        L.conv3x3(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                  r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)
+        # weight gradients: conv k reads D[0:kF), its dy is E slice (5-k) (k=5: slice 0 scaled by s5)
+        for k in range(1, 6):
+            conv = getattr(d, f"b{k}")[0]
+            dw, db = grads[conv.weight], grads[conv.bias]
+            L.conv3x3_wgrad(View(D, 0, k * F_), View(E, (5 - k) * F_, F_), dw, db, N=N, H=H, W=W, OH=H, OW=W,
+                            Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0))
+
+    def _rrdb_chain_forward(self, rrdbs, packs, x0: torch.Tensor, geo, save: bool):
+        """Runs a chain of RRDBs.  x0: dense buffer [N,H,W,5F] whose slice 0 already holds the chain input.
+        Returns (list of dense buffers, output tensor [N,H,W,F])."""
+        N, H, W = geo
+        F_ = self.gen.filters
+        dev = x0.device
+        bufs = [x0]
+        cur = x0
+        n_r = len(rrdbs)
+        for i, rr in enumerate(rrdbs):
+            first = cur
+            for j, d in enumerate(rr.dense_blocks):
+                last = (i == n_r - 1 and j == 2)
+                if last:
+                    nxt = _empty(N, H, W, F_, device=dev)
+                    out = View(nxt)
+                else:
+                    nxt = _empty(N, H, W, 5 * F_, device=dev)
+                    out = View(nxt, 0, F_)
+                self._drb_forward(d, packs[i][j], cur, out, geo, View(first, 0, F_) if j == 2 else None, rr.res_scale)
+                if not last:
+                    bufs.append(nxt)
+                cur = nxt
+        return bufs, cur
+
+    def _rrdb_chain_backward(self, rrdbs, packs, bufs, g_out: torch.Tensor, geo, grads):
+        """g_out: [N,H,W,F] gradient of the chain output.  Returns gradient of the chain input [N,H,W,F]."""
+        N, H, W = geo
+        F_ = self.gen.filters
+        dev = g_out.device
+        n_r = len(rrdbs)
+        # E buffer of block (i,2) must stay alive until block (i,0) finishes (it is the outer residual G)
+        E_next = _empty(N, H, W, 5 * F_, device=dev)
+        E_next[..., :F_].copy_(g_out)
+        result = None
+        for i in range(n_r - 1, -1, -1):
+            rr = rrdbs[i]
+            E_outer = E_next
+            E_cur = E_next
+            for j in (2, 1, 0):
+                D = bufs[3 * i + j]
+                final = (i == 0 and j == 0)
+                if final:
+                    result = _empty(N, H, W, F_, device=dev)
+                    gx = View(result)
+                else:
+                    E_prev = _empty(N, H, W, 5 * F_, device=dev)
+                    gx = View(E_prev, 0, F_)
+                self._drb_backward(rr.dense_blocks[j], packs[i][j], D, E_cur, gx, geo,
+                                   beta_self=(rr.res_scale if j == 2 else 1.0),
+                                   outer_g=(View(E_outer, 0, F_) if j == 0 else None), grads=grads)
+                if not final:
+                    E_cur = E_prev
+            E_next = E_cur
+        return result
+
+    # ------------------------------------------------------------------ whole generator
+    def forward(self, x: torch.Tensor, need_grad: bool):
+        """x: NCHW fp32 CUDA (already power/multiplier-scaled).  Returns (raw NCHW output of conv3, saved)."""
+        g = self.gen
+        if not x.is_cuda:
+            raise RuntimeError("super-resolution_amd: the generator hot path only runs on a ROCm GPU tensor "
+                               "(no CPU fallback; use oracle/ for a CPU check in tests)")
+        self._ensure_packed(need_bwd=False)
+        N, C_, H, W = x.shape
+        assert C_ == g.channels
+        F_ = g.filters
+        dev = x.device
+        x = x.contiguous().float()
+        if C_ == 1:
+            x_nhwc = x.view(N, H, W, 1)
+        else:
+            x_nhwc = _empty(N, H, W, C_, device=dev)
+            L.nchw_to_nhwc(x, View(x_nhwc), N, C_, H, W)
+        geo = (N, H, W)
+        D0 = _empty(N, H, W, 5 * F_, device=dev)
+        # conv1 -> slice 0 of the first dense buffer (= out1, also the trunk skip; models.py:123)
+        L.conv3x3(View(x_nhwc), self.wf(self.idx["conv1"][0]), g.conv1.bias.data, View(D0, 0, F_), N=N, H=H, W=W, OH=H, OW=W,
+                  Cin=C_, Cout=F_)
+        if len(g.res_blocks) > 0:
+            bufs, trunk = self._rrdb_chain_forward(list(g.res_blocks), self.drbs, D0, geo, need_grad)
+            trunk_v = View(trunk)
+        else:
+            bufs, trunk = [D0], D0
+            trunk_v = View(D0, 0, F_)
+        # conv2 + trunk skip (models.py:125-126)
+        feat = _empty(N, H, W, F_, device=dev)
+        L.conv3x3(trunk_v, self.wf(self.idx["conv2"][0]), g.conv2.bias.data, View(feat), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_,
+                  r1=View(D0, 0, F_), beta1=1.0)
+        # upsampling: conv F->4F + LeakyReLU + PixelShuffle(2) fused into the store (models.py:86-90)
+        ups = []
+        cur, h, w = feat, H, W
+        for u in range(g.num_upsample):
+            last_up = (u == g.num_upsample - 1)
+            if last_up and g.num_final_layer_res > 0:
+                nxt = _empty(N, 2 * h, 2 * w, 5 * F_, device=dev)   # doubles as first dense buffer of the final RRDBs
+                yv = View(nxt, 0, F_)
+            else:
+                nxt = _empty(N, 2 * h, 2 * w, F_, device=dev)
+                yv = View(nxt)
+            L.conv3x3(View(cur) if cur.shape[3] == F_ else View(cur, 0, F_), self.wf(self.idx[f"up{u}"][0]), self.ps_bias[u], yv,
+                      N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, ps_out=True, slope=G_SLOPE)
+            ups.append(nxt)
+            cur, h, w = nxt, 2 * h, 2 * w
+        fin = None
+        if g.num_final_layer_res > 0:
+            if g.num_upsample == 0:
+                raise NotImplementedError("num_final_layer_res > 0 requires num_upsample >= 1 in this build")
+            fbufs, fout = self._rrdb_chain_forward(list(g.res_blocks_final), self.drbs_final, cur, (N, h, w), need_grad)
+            pre3 = _empty(N, h, w, F_, device=dev)
+            torch.add(fout, cur[..., :F_], out=pre3)      # out = out3 + out (models.py:130)
+            fin = (fbufs, pre3)
+            cur_v = View(pre3)
+        else:
+            cur_v = View(cur)
+        h3 = _empty(N, h, w, F_, device=dev)
+        L.conv3x3(cur_v, self.wf(self.idx["conv3.0"][0]), g.conv3[0].bias.data, View(h3), N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_,
+                  slope=G_SLOPE)
+        out_nhwc = _empty(N, h, w, C_, device=dev)
+        L.conv3x3(View(h3), self.wf(self.idx["conv3.2"][0]), g.conv3[2].bias.data, View(out_nhwc), N=N, H=h, W=w, OH=h, OW=w,
+                  Cin=F_, Cout=C_)
+        if C_ == 1:
+            out = out_nhwc.view(N, 1, h, w)
+        else:
+            out = _empty(N, C_, h, w, device=dev)
+            L.nhwc_to_nchw(View(out_nhwc), out, N, C_, h, w)
+        saved = None
+        if need_grad:
+            saved = dict(x=x_nhwc, bufs=bufs, trunk=trunk, feat=feat, ups=ups, fin=fin, h3=h3, geo=geo, hr=(h, w))
+        return out, saved
+
+    def backward(self, saved, g_out: torch.Tensor, need_input_grad: bool):
+        """g_out: NCHW gradient of the raw conv3 output.  Returns (dx NCHW or None, {param: grad})."""
+        g = self.gen
+        self._ensure_packed(need_bwd=True)
+        N, H, W = saved["geo"]
+        h, w = saved["hr"]
+        F_, C_ = g.filters, g.channels
+        dev = g_out.device
+        g_out = g_out.contiguous().float()
+        if C_ == 1:
+            go = g_out.view(N, h, w, 1)
+        else:
+            go = _empty(N, h, w, C_, device=dev)
+            L.nchw_to_nhwc(g_out, View(go), N, C_, h, w)
+        grads = {p: torch.empty_like(p) for p in self.params()}
+        ups, h3 = saved["ups"], saved["h3"]
+        fin = saved["fin"]
+        pre3_in = fin[1] if fin is not None else (ups[-1] if ups else saved["feat"])
+        pre3_v = View(pre3_in) if pre3_in.shape[3] == F_ else View(pre3_in, 0, F_)
+
+        # conv3.2 (F -> C) then conv3.0 (F -> F, LeakyReLU)
+        c32, c30 = g.conv3[2], g.conv3[0]
+        L.conv3x3_wgrad(View(h3), View(go), grads[c32.weight], grads[c32.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_)
+        g_h3 = _empty(N, h, w, F_, device=dev)
+        L.conv3x3(View(go), self.wb(self.idx["conv3.2"][1]), None, View(g_h3), N=N, H=h, W=w, OH=h, OW=w, Cin=C_, Cout=F_,
+                  mask=View(h3), mask_slope=G_SLOPE)
+        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_)
+        g_cur = _empty(N, h, w, F_, device=dev)
+        # the tensor feeding conv3.0 is a LeakyReLU output (last upsample stage) unless final RRDBs / no upsampling sit between
+        mask_v = None
+        if fin is None and ups:
+            mask_v = View(ups[-1])
+        L.conv3x3(View(g_h3), self.wb(self.idx["conv3.0"][1]), None, View(g_cur), N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_,
+                  mask=mask_v, mask_slope=G_SLOPE)
+        if fin is not None:
+            fbufs, _ = fin
+            g_chain = self._rrdb_chain_backward(list(g.res_blocks_final), self.drbs_final, fbufs, g_cur, (N, h, w), grads)
+            # out = out3 + out: both paths; then LeakyReLU' of the upsample output
+            up_last = ups[-1]
+            g_sum = g_chain + g_cur
+            g_cur = g_sum * torch.where(up_last[..., :F_] > 0, 1.0, G_SLOPE)
+
+        # upsampling stages, last to first
+        hh, ww = h, w
+        for u in range(g.num_upsample - 1, -1, -1):
+            conv = g.upsampling[3 * u]
+            hh, ww = hh // 2, ww // 2
+            xin = ups[u - 1] if u > 0 else saved["feat"]
+            xin_v = View(xin) if xin.shape[3] == F_ else View(xin, 0, F_)
+            L.conv3x3_wgrad(xin_v, View(g_cur), grads[conv.weight], grads[conv.bias], N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=F_, Cout=4 * F_,
+                            dy_mode=L.IN_UNSHUFFLE)
+            g_prev = _empty(N, hh, ww, F_, device=dev)
+            L.conv3x3(View(g_cur), self.wb(self.idx[f"up{u}"][1]), None, View(g_prev), N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=4 * F_, Cout=F_,
+                      in_mode=L.IN_UNSHUFFLE, mask=(View(ups[u - 1]) if u > 0 else None), mask_slope=G_SLOPE)
+            g_cur = g_prev
+        g_feat = g_cur                                   # gradient of out1 + out2
+        # conv2
+        trunk = saved["trunk"]
+        bufs = saved["bufs"]
+        D0 = bufs[0]
+        trunk_v = View(trunk) if trunk.shape[3] == F_ else View(trunk, 0, F_)
+        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
+        g_trunk = _empty(N, H, W, F_, device=dev)
+        L.conv3x3(View(g_feat), self.wb(self.idx["conv2"][1]), None, View(g_trunk), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
+        if len(g.res_blocks) > 0:
+            g_out1 = self._rrdb_chain_backward(list(g.res_blocks), self.drbs, bufs, g_trunk, (N, H, W), grads)
+        else:
+            g_out1 = g_trunk
+        g_out1 = g_out1 + g_feat                         # trunk skip (models.py:126)
+        # conv1
+        L.conv3x3_wgrad(View(saved["x"]), View(g_out1), grads[g.conv1.weight], grads[g.conv1.bias], N=N, H=H, W=W, OH=H, OW=W,
+                        Cin=C_, Cout=F_)
+        dx = None
+        if need_input_grad:
+            dxn = _empty(N, H, W, C_, device=dev)
+            L.conv3x3(View(g_out1), self.wb(self.idx["conv1"][1]), None, View(dxn), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=C_)
+            if C_ == 1:
+                dx = dxn.view(N, 1, H, W)
+            else:
+                dx = _empty(N, C_, H, W, device=dev)
+                L.nhwc_to_nchw(View(dxn), dx, N, C_, H, W)
+        return dx, grads
+
+
+class _GeneratorFn(torch.autograd.Function):
+    """raw = conv3(upsample(conv1(x) + conv2(RRDB^R(conv1(x))))) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, engine: GeneratorEngine, x, *params):
+        need = any(ctx.needs_input_grad)
+        out, saved = engine.forward(x.detach(), need_grad=need)
+        ctx.engine = engine
+        ctx.saved = saved
+        ctx.x_req = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        if ctx.saved is None:
+            raise RuntimeError("generator backward called but forward ran without grad")
+        eng = ctx.engine
+        dx, grads = eng.backward(ctx.saved, g_out, ctx.x_req)
+        ctx.saved = None
+        return (None, dx) + tuple(grads[p] for p in eng.params())
+
+
+def generator_raw(engine: GeneratorEngine, x: torch.Tensor) -> torch.Tensor:
+    return _GeneratorFn.apply(engine, x, *engine.params())

@@ -1,0 +1,241 @@
+"""Drop-in for the class surface of the reference's ``models.py`` on MI355X.
+
+Same constructor signatures, attributes (``.thres``, ``.srs``, ``.power``, ``.multiplier``, ``.output_shape``),
+``nn.Module`` protocol and ``state_dict`` keys as /root/reference/models.py, so ``from models import *`` users
+(esrgan.py:17, evaluation/eval.py:11, evaluation/demo.py:17) and ``.pth`` checkpoints interchange both ways.
+Parameters stay canonical OIHW fp32 ``nn.Conv2d`` weights (``weight_reset``/``uniform_reset``/``plot_grad_flow``
+keep working); the arithmetic runs in the gfx950 kernels of ``libsrk.so``.  There is no CPU fallback: a non-GPU
+input raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .engine import GeneratorEngine, generator_raw
+
+
+class Conv3x3(nn.Conv2d):
+    """``nn.Conv2d(cin, cout, 3, stride, 1)`` whose forward is the srk kernel (NCHW in / NCHW out).
+
+    Inside GeneratorRRDB / Markovian_Discriminator the parent runs fused NHWC pipelines and never calls this
+    forward; it exists so that any other composition of the reference's building blocks still runs on the HIP
+    path (and stays twice differentiable)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True):
+        if kernel_size != 3 or padding != 1 or stride not in (1, 2):
+            raise NotImplementedError("only the reference's 3x3 / pad 1 / stride 1|2 convolutions are implemented")
+        super().__init__(in_channels, out_channels, 3, stride, 1, bias=bias)
+
+    def forward(self, x):
+        y = ops.conv_pre(ops.to_nhwc(x.float()), self.weight, self.bias, self.stride[0], 1.0)
+        return ops.to_nchw(y)
+
+
+class DenseResidualBlock(nn.Module):
+    """models.py:9-41.  Parameter container; GeneratorRRDB runs it concat-free (engine.py)."""
+
+    def __init__(self, filters, res_scale=0.2, drop_rate=0):
+        super().__init__()
+        self.res_scale = res_scale
+        if drop_rate > 0:
+            raise NotImplementedError("Dropout2d inside the dense block (drop_rate > 0) is out of scope of this build")
+
+        def block(in_features, non_linearity=True):
+            layers = [Conv3x3(in_features, filters, 3, 1, 1, bias=True)]
+            if non_linearity:
+                layers += [nn.LeakyReLU()]
+            return nn.Sequential(*layers)
+
+        self.b1 = block(in_features=1 * filters)
+        self.b2 = block(in_features=2 * filters)
+        self.b3 = block(in_features=3 * filters)
+        self.b4 = block(in_features=4 * filters)
+        self.b5 = block(in_features=5 * filters, non_linearity=False)
+        self.drop = False
+        self.blocks = [self.b1, self.b2, self.b3, self.b4, self.b5]
+
+    def forward(self, x):
+        inputs = x
+        for block in self.blocks:
+            out = block(inputs)
+            inputs = torch.cat([inputs, out], 1)
+        return out.mul(self.res_scale) + x
+
+
+class ResidualInResidualDenseBlock(nn.Module):
+    """models.py:44-53 (inner blocks keep res_scale 0.2: the reference does not forward its argument)."""
+
+    def __init__(self, filters, res_scale=0.2, drop_rate=0):
+        super().__init__()
+        self.res_scale = res_scale
+        self.dense_blocks = nn.Sequential(
+            DenseResidualBlock(filters, drop_rate=drop_rate), DenseResidualBlock(filters, drop_rate=drop_rate),
+            DenseResidualBlock(filters, drop_rate=drop_rate))
+
+    def forward(self, x):
+        return self.dense_blocks(x).mul(self.res_scale) + x
+
+
+class GeneratorRRDB(nn.Module):
+    """models.py:56-135, default upsampling branch (conv F->4F, LeakyReLU, PixelShuffle(2))."""
+
+    def __init__(self, channels=1, filters=64, num_res_blocks=10, num_upsample=1, power=1, multiplier=1, drop_rate=0,
+                 res_scale=0.2, use_transposed_conv=False, fully_tconv_upsample=False, num_final_layer_res=0, uniform_init=False):
+        super().__init__()
+        if use_transposed_conv or fully_tconv_upsample:
+            raise NotImplementedError("the ConvTranspose2d upsampling branches (models.py:70-83) are outside the hot path of this build")
+        if filters % 8 != 0:
+            raise NotImplementedError("filters must be a multiple of 8 (8-channel K chunks of the MFMA kernels)")
+        self.channels, self.filters, self.num_upsample = channels, filters, num_upsample
+        self.num_final_layer_res = num_final_layer_res
+        self.conv1 = Conv3x3(channels, filters, kernel_size=3, stride=1, padding=1)
+        self.res_blocks = nn.Sequential(*[ResidualInResidualDenseBlock(filters, res_scale=res_scale, drop_rate=drop_rate)
+                                          for _ in range(num_res_blocks)])
+        self.conv2 = Conv3x3(filters, filters, kernel_size=3, stride=1, padding=1)
+        upsample_layers = []
+        for _ in range(num_upsample):
+            upsample_layers += [Conv3x3(filters, filters * 4, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                                nn.PixelShuffle(upscale_factor=2)]
+        self.upsampling = nn.Sequential(*upsample_layers)
+        if num_final_layer_res > 0:
+            self.res_blocks_final = nn.Sequential(*[ResidualInResidualDenseBlock(filters, res_scale=res_scale, drop_rate=drop_rate)
+                                                    for _ in range(num_final_layer_res)])
+        self.conv3 = nn.Sequential(Conv3x3(filters, filters, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                                   Conv3x3(filters, channels, kernel_size=3, stride=1, padding=1))
+        self.thres = 0
+        self.power = nn.Parameter(torch.Tensor([power]), False)
+        self.multiplier = nn.Parameter(torch.Tensor([multiplier]), False)
+        self._scalars = None
+        self._engine = GeneratorEngine(self)
+        if uniform_init:
+            self.init_conv2d()
+
+    def init_conv2d(self):
+        # models.py:108-112: children() is not recursive -> only conv1 / conv2 are touched
+        for c in self.children():
+            if isinstance(c, nn.Conv2d):
+                nn.init.xavier_uniform_(c.weight)
+                nn.init.constant_(c.bias, 0.)
+
+    def _power_multiplier(self):
+        """Host copies of the two frozen scalars, refreshed only when the Parameters change (the reference
+        syncs on them every forward, models.py:116,133)."""
+        key = (self.power.data_ptr(), self.power._version, self.multiplier.data_ptr(), self.multiplier._version)
+        if self._scalars is None or self._scalars[0] != key:
+            self._scalars = (key, float(self.power.item()), float(self.multiplier.item()))
+        return self._scalars[1], self._scalars[2]
+
+    def out(self, x, pow=1.0):
+        lambd = float(self.thres) ** float(pow)
+        if self.training:
+            return F.hardshrink(x, lambd=lambd)
+        return F.hardshrink(F.relu(x), lambd=lambd)
+
+    def forward(self, x):
+        power, mult = self._power_multiplier()
+        if power != 1.0 or mult != 1.0:
+            x = self.multiplier * (x ** self.power)
+        out = generator_raw(self._engine, x)
+        if mult != 1.0:
+            out = out / self.multiplier
+        self.srs = self.out(out, power)
+        if power != 1.0:
+            out = F.relu(out) ** (1 / self.power)
+        return self.out(out)
+
+
+def discriminator_block(in_filters, out_filters, stride=(1, 2)):
+    """models.py:140-146."""
+    return [Conv3x3(in_filters, out_filters, kernel_size=3, stride=stride[0], padding=1), nn.LeakyReLU(0.2, inplace=True),
+            Conv3x3(out_filters, out_filters, kernel_size=3, stride=stride[1], padding=1), nn.LeakyReLU(0.2, inplace=True)]
+
+
+class Markovian_Discriminator(nn.Module):
+    """PatchGAN discriminator, models.py:149-174.  Runs as a pre-activation NHWC chain
+    z_l = conv(lrelu_0.2(z_{l-1})) on the srk kernels; twice differentiable w.r.t. the input (gradient penalty)."""
+
+    def __init__(self, input_shape, channels=[16, 32, 32, 64]):
+        super().__init__()
+        self.channels = channels
+        self.input_shape = input_shape
+        in_channels, in_height, in_width = self.input_shape
+
+        def stride2(x):
+            return int(np.ceil(x / 2))
+        patch_h, patch_w = in_height, in_width
+        layers = []
+        in_filters = in_channels
+        for out_filters in self.channels:
+            layers.extend(discriminator_block(in_filters, out_filters))
+            in_filters = out_filters
+            patch_h, patch_w = stride2(patch_h), stride2(patch_w)
+        layers.append(Conv3x3(in_filters, 1, kernel_size=3, stride=1, padding=1))
+        self.output_shape = (1, patch_h, patch_w)
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, img, *args):
+        z = ops.to_nhwc(img.float())
+        in_slope = 1.0
+        for m in self.model:
+            if isinstance(m, nn.Conv2d):
+                z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope)
+                in_slope = 1.0
+            elif isinstance(m, nn.LeakyReLU):
+                in_slope = m.negative_slope        # applied while the next conv stages its input
+            else:
+                raise RuntimeError("unexpected layer in Markovian_Discriminator.model")
+        return ops.to_nchw(z)
+
+
+class Standard_Discriminator(Markovian_Discriminator):
+    """models.py:177-186: patch trunk without its last conv, plus a two-layer FC head (PyTorch Linear)."""
+
+    def __init__(self, input_shape, channels):
+        super().__init__(input_shape, channels)
+        self.model = self.model[:-1]
+        self.fc = nn.Sequential(nn.Linear(self.channels[-1] * self.output_shape[-2] * self.output_shape[-1], 1024), nn.ReLU(),
+                                nn.Linear(1024, 1))
+        self.output_shape = (1,)
+
+    def forward(self, img, *args):
+        z = ops.to_nhwc(img.float())
+        in_slope = 1.0
+        for m in self.model:
+            if isinstance(m, nn.Conv2d):
+                z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope)
+                in_slope = 1.0
+            else:
+                in_slope = m.negative_slope
+        z = F.leaky_relu(z, in_slope)                 # trailing LeakyReLU of the last block
+        return self.fc(ops.to_nchw(z).reshape(img.shape[0], -1))
+
+
+class SumPool2d(nn.Module):
+    """models.py:297-305: k*k * AvgPool2d(k)."""
+
+    def __init__(self, k=4, stride=None):
+        super().__init__()
+        if stride is not None and stride != k:
+            raise NotImplementedError("SumPool2d with stride != k is not used by the reference's train path")
+        self.k = k
+        self.kernel_size = k * k
+
+    def forward(self, x):
+        return ops.sum_pool(x, self.k)
+
+
+def weight_reset(m):
+    """models.py:375-378."""
+    if isinstance(m, nn.Conv2d) or isinstance(m, nn.Linear):
+        m.reset_parameters()
+
+
+def uniform_reset(m):
+    """models.py:380-384."""
+    if isinstance(m, nn.Conv2d):
+        nn.init.xavier_uniform_(m.weight)
+        nn.init.constant_(m.bias, 0.)

@@ -1,0 +1,160 @@
+"""GPU parity of the drop-in modules against the reference-generated golden fixtures and the CPU oracle.
+Tolerance: BASELINE.json's 1e-3 relative (fp32) on outputs; gradients 2e-3 of the tensor's max-abs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import esrgan_oracle as O  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+OUT_TOL = 1e-3
+GRAD_TOL = 2e-3
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _load_closed_form(mod, gain=1.0):
+    sd = O.closed_form_fill({k: v.cpu() for k, v in mod.state_dict().items()}, gain=gain)
+    mod.load_state_dict(sd)
+    return sd
+
+
+@pytest.mark.parametrize("name", ["G4_gen_f16_r1_u2", "G6_gen_resscale01", "G4b_gen_c3_f16_r1_u1", "G5_config0"])
+def test_generator_golden(srk, golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    c, f, r, u = [int(v) for v in d["cfg"]]
+    gen = srk.GeneratorRRDB(c, filters=f, num_res_blocks=r, num_upsample=u, res_scale=float(d["res_scale"])).cuda()
+    _load_closed_form(gen, float(d["gain"]))
+    assert int(d["n_keys"]) == len(gen.state_dict())
+    x = torch.from_numpy(d["x"]).cuda()
+    gen.train()
+    y = gen(x)
+    assert rel(y.cpu(), torch.from_numpy(d["y_train"])) < OUT_TOL
+    assert rel(gen.srs.cpu(), torch.from_numpy(d["srs"])) < OUT_TOL
+    loss = (y - torch.from_numpy(d["target"]).cuda()).abs().mean()
+    assert abs(loss.item() - float(d["loss"])) < 1e-4 * max(1.0, float(d["loss"]))
+    loss.backward()
+    checked = 0
+    for k, p in gen.named_parameters():
+        key = "grad." + k
+        if key in d.files:
+            ref = torch.from_numpy(d[key])
+            assert rel(p.grad.cpu(), ref) < GRAD_TOL, k
+            checked += 1
+    if name != "G5_config0":
+        assert checked == len(list(gen.parameters())) - 2
+    gen.eval()
+    with torch.no_grad():
+        ye = gen(x)
+    ye_ref = torch.from_numpy(d["y_eval"])
+    assert (ye.cpu() - ye_ref).abs().max().item() < OUT_TOL * max(ye_ref.abs().max().item(), torch.from_numpy(d["y_train"]).abs().max().item())
+    assert torch.equal(ye, torch.relu(ye))
+
+
+def test_generator_vs_oracle_ragged_and_final_blocks(srk):
+    """80x80-style ragged tiles (not multiples of the 8x16 tile), batch 3, final-layer RRDBs, input gradient."""
+    torch.manual_seed(0)
+    gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=2, num_upsample=1, res_scale=0.1, num_final_layer_res=1).cuda()
+    sd = _load_closed_form(gen)
+    x = (torch.rand(3, 1, 20, 13) * 2).requires_grad_(True)
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, x, 2, 1, 0.1, training=True, num_final_layer_res=1)
+    tgt = torch.rand_like(yo)
+    (yo - tgt).abs().mean().backward()
+    xg = x.detach().cuda().requires_grad_(True)
+    y = gen(xg)
+    assert rel(y.detach().cpu(), yo.detach()) < OUT_TOL
+    (y - tgt.cuda()).abs().mean().backward()
+    assert rel(xg.grad.cpu(), x.grad) < GRAD_TOL
+    for k, p in gen.named_parameters():
+        if p.grad is not None:
+            assert rel(p.grad.cpu(), sdo[k].grad) < GRAD_TOL, k
+
+
+def test_generator_power_multiplier(srk):
+    gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1, power=0.5, multiplier=2.0).cuda()
+    sd = _load_closed_form(gen)
+    sd["power"] = torch.tensor([0.5]); sd["multiplier"] = torch.tensor([2.0])
+    gen.load_state_dict(sd)
+    x = torch.rand(2, 1, 8, 8) + 0.1
+    yo, so = O.generator_forward(sd, x, 1, 1, 0.2, training=True)
+    y = gen(x.cuda())
+    assert rel(y.cpu(), yo) < OUT_TOL and rel(gen.srs.cpu(), so) < OUT_TOL
+
+
+def test_drb_golden_generic_path(srk, golden_dir):
+    """DenseResidualBlock used stand-alone (generic Conv3x3 path) against G3 incl. all gradients."""
+    d = np.load(os.path.join(golden_dir, "G3_drb16.npz"))
+    drb = srk.DenseResidualBlock(16).cuda()
+    _load_closed_form(drb)
+    x = torch.from_numpy(d["x"]).cuda().requires_grad_(True)
+    y = drb(x)
+    assert rel(y.detach().cpu(), torch.from_numpy(d["y"])) < OUT_TOL
+    y.backward(torch.from_numpy(d["gout"]).cuda())
+    assert rel(x.grad.cpu(), torch.from_numpy(d["dx"])) < GRAD_TOL
+    for k, p in drb.named_parameters():
+        assert rel(p.grad.cpu(), torch.from_numpy(d["grad." + k])) < GRAD_TOL, k
+
+
+def test_discriminator_golden_with_gradient_penalty(srk, golden_dir):
+    """Markovian_Discriminator forward, relativistic D loss and the gradient penalty's double backward
+    (esrgan.py:569-616) against G7."""
+    d = np.load(os.path.join(golden_dir, "G7_discriminator.npz"))
+    D = srk.Markovian_Discriminator((1, 32, 32), [16, 32, 32, 64]).cuda()
+    _load_closed_form(D, gain=2.0)
+    assert tuple(D.output_shape) == (1, 2, 2)
+    gt, gen, eps = [torch.from_numpy(d[k]).cuda() for k in ("gt", "gen", "eps")]
+    pred_real = D(gt, None)
+    pred_fake = D(gen, None)
+    assert rel(pred_real.detach().cpu(), torch.from_numpy(d["pred_real"])) < OUT_TOL
+    assert rel(pred_fake.detach().cpu(), torch.from_numpy(d["pred_fake"])) < OUT_TOL
+    crit = torch.nn.BCEWithLogitsLoss()
+    valid = torch.ones(3, *D.output_shape, device="cuda"); fake = torch.zeros_like(valid)
+    loss_D = (crit(1e-7 + pred_real - pred_fake.mean(0, keepdim=True), valid) +
+              crit(1e-7 + pred_fake - pred_real.mean(0, keepdim=True), fake)) / 2
+    interp = (eps * gt + (1 - eps) * gen)
+    interp.requires_grad = True
+    pi = D(interp, None)
+    grads = torch.autograd.grad(outputs=pi, inputs=interp, grad_outputs=valid, create_graph=True, retain_graph=True, only_inputs=True)[0]
+    assert rel(grads.detach().cpu(), torch.from_numpy(d["input_grad_gp"])) < GRAD_TOL
+    gp = ((grads.view(3, -1).norm(2, dim=1) - 1) ** 2).mean() * 0.01 / 2
+    tot = loss_D + gp
+    assert abs(gp.item() - float(d["gp"])) < 1e-3 * float(d["gp"])
+    assert abs(tot.item() - float(d["loss"])) < 1e-4
+    tot.backward()
+    for k, p in D.named_parameters():
+        assert rel(p.grad.cpu(), torch.from_numpy(d["grad." + k])) < GRAD_TOL, k
+
+
+def test_discriminator_ragged_shapes(srk):
+    for shp in [(1, 80, 80), (1, 75, 75), (3, 40, 24)]:
+        D = srk.Markovian_Discriminator(shp, [16, 32, 32, 64]).cuda()
+        sd = _load_closed_form(D, gain=2.0)
+        x = torch.rand(2, *shp)
+        ref = O.discriminator_forward(sd, x)
+        y = D(x.cuda())
+        assert tuple(y.shape[1:]) == tuple(D.output_shape) == O.discriminator_output_shape(shp)
+        assert rel(y.detach().cpu(), ref) < OUT_TOL
+
+
+def test_sumpool_module(srk):
+    x = torch.rand(2, 1, 16, 16).requires_grad_(True)
+    ref = O.sum_pool(x, 4)
+    ref.sum().backward()
+    xg = x.detach().cuda().requires_grad_(True)
+    y = srk.SumPool2d(4)(xg)
+    assert torch.allclose(y.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    y.sum().backward()
+    assert torch.allclose(xg.grad.cpu(), x.grad)
+
+
+def test_cpu_tensor_fails_loudly(srk):
+    gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1)
+    with pytest.raises(RuntimeError):
+        gen(torch.rand(1, 1, 8, 8))
