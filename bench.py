@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ESRGAN training hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload g_only|gan] [--batch B]
+
+A "step" is one pass of the hot path over one synthetic batch of jet images (64x64 LR -> 256x256 HR,
+GeneratorRRDB(1, 64, 23, num_upsample=2)):
+  g_only : the reference's warm-up iteration (esrgan.py:416-439): G forward, L1, backward, Adam  (BASELINE configs[1])
+  gan    : full iteration (esrgan.py:457-626): G phase through two patch discriminators + D phase with
+           relativistic BCE and gradient penalty, three Adam steps                             (BASELINE configs[2])
+Inputs are generated on the GPU before the timed region.  For N > 1 launch with
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: one process per GPU, weak scaling
+(fixed per-GPU batch), gradients averaged with RCCL all-reduce overlapped with the backward pass.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HR = 256
+FACTOR = 4
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("SRK_WORKLOAD", "g_only"), choices=["g_only", "gan"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
+    ap.add_argument("--res-blocks", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket conv launches with events")
+    return ap.parse_args()
+
+
+def synth_batch(n, device, seed):
+    """hr = 10*U(0,1)*Bernoulli(0.1); lr = SumPool2d(4)(hr) (datasets.py:227,247)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    hr = 10.0 * torch.rand(n, 1, HR, HR, generator=g) * (torch.rand(n, 1, HR, HR, generator=g) < 0.1).float()
+    hr = hr.to(device)
+    lr = 16.0 * torch.nn.functional.avg_pool2d(hr, FACTOR)
+    return lr.contiguous(), hr.contiguous()
+
+
+def cpu_baseline(res_blocks, workload):
+    """Times the CPU oracle (a port of the reference's step, oracle/esrgan_oracle.py) on this box's host cores
+    on a bounded sample; baseline only."""
+    from oracle import esrgan_oracle as O
+    n = 2
+    cores = torch.get_num_threads()
+    sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
+    params = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999))
+    lr, hr = O.jet_images(n, 1, HR, HR, 1234, FACTOR)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        y, _ = O.generator_forward(params, lr, res_blocks, 2, 0.2, training=True)
+        O.warmup_loss(y, hr).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / len(times[1:])
+    return {"value": n * HR * HR / dt, "unit": "HR-px/s", "cores": cores, "kind": "port",
+            "sample": f"G-only step (fwd+L1+bwd+Adam) of the same generator, batch {n}, 1 warm-up + 2 timed iters, "
+                      f"{dt*1e3:.0f} ms/iter, torch CPU fp32"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    sr = importlib.import_module("super-resolution_amd")
+    from importlib import import_module
+    train = import_module("super-resolution_amd.train")
+    L = sr._lib
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    batch = args.batch or (16 if args.workload == "g_only" else 32)
+    torch.manual_seed(0)                                  # identical replicas on every rank
+    stepper = train.Stepper(workload=args.workload, res_blocks=args.res_blocks, device=dev, hr=HR, factor=FACTOR,
+                            distributed=(world > 1))
+    lr_img, hr_img = synth_batch(batch, dev, 1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step(lr_img, hr_img)
+    barrier()
+    if not args.no_kernel_timing:
+        L.KernelTimer.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(lr_img, hr_img)
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = None if args.no_kernel_timing else L.KernelTimer.stop()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    ms = dt / args.steps * 1e3
+    value = world * batch * HR * HR * args.steps / dt
+
+    if rank == 0:
+        roof = None
+        if ktimes:
+            dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"])
+            name, st = dom
+            ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(name)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
+                    "avg_gflop_per_launch": round(st["flops"] / st["n"] / 1e9, 3),
+                    "conv_time_share": round(sum(v["ms"] for v in ktimes.values()) / (dt * 1e3), 4)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(args.res_blocks, args.workload)
+        out = {
+            "metric": "HR-pixels/s + ms/iter (G+D step), 64->256 jet images" if args.workload == "gan"
+                      else "HR-pixels/s + ms/iter (G-only warm-up step), 64->256 jet images",
+            "value": value, "unit": "HR-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GeneratorRRDB(1,64,{args.res_blocks},num_upsample=2) 64x64->256x256, "
+                                   f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
+                                                           if args.workload == "gan" else ", L1 + Adam"),
+                       "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
+                       "generator_train_gflop_per_image": 971.4},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

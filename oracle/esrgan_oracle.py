@@ -156,8 +156,7 @@ def generator_state_shapes(channels=1, filters=64, num_res_blocks=10, num_upsamp
     """state_dict key -> shape for GeneratorRRDB (models.py:58-106)."""
     F_ = filters
     sh = {"power": (1,), "multiplier": (1,),
-          "conv1.weight": (F_, channels, 3, 3), "conv1.bias": (F_,),
-          "conv2.weight": (F_, F_, 3, 3), "conv2.bias": (F_,)}
+          "conv1.weight": (F_, channels, 3, 3), "conv1.bias": (F_,)}
 
     def add_rrdbs(name, n):
         for i in range(n):
@@ -167,6 +166,8 @@ def generator_state_shapes(channels=1, filters=64, num_res_blocks=10, num_upsamp
                     sh[p + ".weight"] = (F_, k * F_, 3, 3)
                     sh[p + ".bias"] = (F_,)
     add_rrdbs("res_blocks", num_res_blocks)
+    sh["conv2.weight"] = (F_, F_, 3, 3)
+    sh["conv2.bias"] = (F_,)
     for u in range(num_upsample):
         sh[f"upsampling.{3*u}.weight"] = (4 * F_, F_, 3, 3)
         sh[f"upsampling.{3*u}.bias"] = (4 * F_,)

@@ -115,6 +115,45 @@ class View:
         assert 0 <= coff and coff + self.C <= self.ldc
 
 
+class KernelTimer:
+    """Optional per-launch timing of the conv kernels with HIP events on the launching stream (bench.py's
+    roofline leg).  Off by default; when on, every srk_conv3x3 / srk_conv3x3_wgrad call is bracketed by two
+    events and attributed to the kernel template the C side dispatches to (same names rocprofv3 reports)."""
+    active = False
+    records = []
+
+    @classmethod
+    def start(cls):
+        cls.records = []
+        cls.active = True
+
+    @classmethod
+    def stop(cls):
+        cls.active = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in cls.records:
+            st = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0})
+            st["ms"] += e0.elapsed_time(e1)
+            st["flops"] += flops
+            st["n"] += 1
+        cls.records = []
+        return out
+
+    @classmethod
+    def bracket(cls, name, flops):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cls.records.append((name, flops, e0, e1))
+        return e0, e1
+
+
+def _conv_kernel_name(a) -> str:
+    """Mirror of the dispatch in srk_conv.hip (srk_conv3x3)."""
+    vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
+    bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
+    return f"conv3x3_f32_kernel<{bn}, {a.stride}, {a.in_mode}, {'true' if vec else 'false'}>"
+
+
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
             ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
             mask: View = None, mask_slope=1.0, in_slope=1.0):
@@ -133,6 +172,12 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, C
     a.slope = slope
     if mask is not None:
         a.mask, a.m_ldc, a.m_coff, a.mask_slope = mask.t.data_ptr(), mask.ldc, mask.coff, mask_slope
+    if KernelTimer.active:
+        e0, e1 = KernelTimer.bracket(_conv_kernel_name(a), 2.0 * N * OH * OW * Cout * Cin * 9)
+        e0.record()
+        check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
+        e1.record()
+        return
     check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
 
 
@@ -160,6 +205,12 @@ def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, C
     check(lib().srk_conv3x3_wgrad_workspace(C.byref(a), C.byref(nbytes)), "srk_conv3x3_wgrad_workspace")
     ws = _workspace(nbytes.value, x.t.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    if KernelTimer.active:
+        e0, e1 = KernelTimer.bracket(f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce", 2.0 * N * OH * OW * Cout * Cin * 9)
+        e0.record()
+        check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
+        e1.record()
+        return
     check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
 
 

@@ -61,6 +61,51 @@ class GeneratorEngine:
     def __init__(self, gen):
         self.gen = gen
         self._sig = None
+        self._sync = False
+        self._grad_scale = 1.0
+
+    # ------------------------------------------------------------------ data-parallel gradient exchange
+    def enable_grad_sync(self, enabled: bool = True):
+        """Average weight gradients across ranks (RCCL all-reduce via torch.distributed) inside backward().
+        Gradients are produced into one flat buffer; each bucket (tail convs, every RRDB, conv1) is reduced with an
+        asynchronous all-reduce as soon as its last wgrad has been launched, so the exchange of RRDB i overlaps the
+        backward convolutions of RRDBs i-1..0."""
+        self._sync = enabled
+        self._grad_scale = 1.0
+        if enabled:
+            import torch.distributed as dist
+            self._grad_scale = 1.0 / dist.get_world_size()   # folded into the wgrad reduction; the exchange is a SUM
+
+    def _alloc_grads(self, device):
+        ps = self.params()
+        sizes = [p.numel() for p in ps]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        grads, off, offs = {}, 0, []
+        for p, n in zip(ps, sizes):
+            grads[p] = flat[off:off + n].view_as(p)
+            offs.append(off)
+            off += n
+        offs.append(off)
+        R = len(self.gen.res_blocks)
+        # param-index ranges: conv1 | RRDB 0..R-1 (30 tensors each) | tail (conv2, upsampling, final RRDBs, conv3)
+        self._bucket = {"conv1": (offs[0], offs[2]), "tail": (offs[2 + 30 * R], offs[-1])}
+        for i in range(R):
+            self._bucket[i] = (offs[2 + 30 * i], offs[2 + 30 * (i + 1)])
+        self._flat_grad = flat
+        self._works = []
+        return grads
+
+    def _reduce_bucket(self, key):
+        if not self._sync:
+            return
+        import torch.distributed as dist
+        a, b = self._bucket[key]
+        self._works.append(dist.all_reduce(self._flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _finish_reduce(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     # ------------------------------------------------------------------ parameter bookkeeping
     def _conv_modules(self):
@@ -204,7 +249,7 @@ class GeneratorEngine:
             conv = getattr(d, f"b{k}")[0]
             dw, db = grads[conv.weight], grads[conv.bias]
             L.conv3x3_wgrad(View(D, 0, k * F_), View(E, (5 - k) * F_, F_), dw, db, N=N, H=H, W=W, OH=H, OW=W,
-                            Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0))
+                            Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0) * self._grad_scale)
 
     def _rrdb_chain_forward(self, rrdbs, packs, x0: torch.Tensor, geo, save: bool):
         """Runs a chain of RRDBs.  x0: dense buffer [N,H,W,5F] whose slice 0 already holds the chain input.
@@ -231,7 +276,7 @@ class GeneratorEngine:
                 cur = nxt
         return bufs, cur
 
-    def _rrdb_chain_backward(self, rrdbs, packs, bufs, g_out: torch.Tensor, geo, grads):
+    def _rrdb_chain_backward(self, rrdbs, packs, bufs, g_out: torch.Tensor, geo, grads, sync=False):
         """g_out: [N,H,W,F] gradient of the chain output.  Returns gradient of the chain input [N,H,W,F]."""
         N, H, W = geo
         F_ = self.gen.filters
@@ -259,6 +304,8 @@ class GeneratorEngine:
                                    outer_g=(View(E_outer, 0, F_) if j == 0 else None), grads=grads)
                 if not final:
                     E_cur = E_prev
+            if sync:
+                self._reduce_bucket(i)
             E_next = E_cur
         return result
 
@@ -351,7 +398,7 @@ class GeneratorEngine:
         else:
             go = _empty(N, h, w, C_, device=dev)
             L.nchw_to_nhwc(g_out, View(go), N, C_, h, w)
-        grads = {p: torch.empty_like(p) for p in self.params()}
+        grads = self._alloc_grads(dev)
         ups, h3 = saved["ups"], saved["h3"]
         fin = saved["fin"]
         pre3_in = fin[1] if fin is not None else (ups[-1] if ups else saved["feat"])
@@ -359,11 +406,11 @@ class GeneratorEngine:
 
         # conv3.2 (F -> C) then conv3.0 (F -> F, LeakyReLU)
         c32, c30 = g.conv3[2], g.conv3[0]
-        L.conv3x3_wgrad(View(h3), View(go), grads[c32.weight], grads[c32.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_)
+        L.conv3x3_wgrad(View(h3), View(go), grads[c32.weight], grads[c32.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_, scale=self._grad_scale)
         g_h3 = _empty(N, h, w, F_, device=dev)
         L.conv3x3(View(go), self.wb(self.idx["conv3.2"][1]), None, View(g_h3), N=N, H=h, W=w, OH=h, OW=w, Cin=C_, Cout=F_,
                   mask=View(h3), mask_slope=G_SLOPE)
-        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_)
+        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, scale=self._grad_scale)
         g_cur = _empty(N, h, w, F_, device=dev)
         # the tensor feeding conv3.0 is a LeakyReLU output (last upsample stage) unless final RRDBs / no upsampling sit between
         mask_v = None
@@ -387,7 +434,7 @@ class GeneratorEngine:
             xin = ups[u - 1] if u > 0 else saved["feat"]
             xin_v = View(xin) if xin.shape[3] == F_ else View(xin, 0, F_)
             L.conv3x3_wgrad(xin_v, View(g_cur), grads[conv.weight], grads[conv.bias], N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=F_, Cout=4 * F_,
-                            dy_mode=L.IN_UNSHUFFLE)
+                            dy_mode=L.IN_UNSHUFFLE, scale=self._grad_scale)
             g_prev = _empty(N, hh, ww, F_, device=dev)
             L.conv3x3(View(g_cur), self.wb(self.idx[f"up{u}"][1]), None, View(g_prev), N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=4 * F_, Cout=F_,
                       in_mode=L.IN_UNSHUFFLE, mask=(View(ups[u - 1]) if u > 0 else None), mask_slope=G_SLOPE)
@@ -398,17 +445,19 @@ class GeneratorEngine:
         bufs = saved["bufs"]
         D0 = bufs[0]
         trunk_v = View(trunk) if trunk.shape[3] == F_ else View(trunk, 0, F_)
-        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
+        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_, scale=self._grad_scale)
         g_trunk = _empty(N, H, W, F_, device=dev)
         L.conv3x3(View(g_feat), self.wb(self.idx["conv2"][1]), None, View(g_trunk), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
+        self._reduce_bucket("tail")
         if len(g.res_blocks) > 0:
-            g_out1 = self._rrdb_chain_backward(list(g.res_blocks), self.drbs, bufs, g_trunk, (N, H, W), grads)
+            g_out1 = self._rrdb_chain_backward(list(g.res_blocks), self.drbs, bufs, g_trunk, (N, H, W), grads, sync=True)
         else:
             g_out1 = g_trunk
         g_out1 = g_out1 + g_feat                         # trunk skip (models.py:126)
         # conv1
         L.conv3x3_wgrad(View(saved["x"]), View(g_out1), grads[g.conv1.weight], grads[g.conv1.bias], N=N, H=H, W=W, OH=H, OW=W,
-                        Cin=C_, Cout=F_)
+                        Cin=C_, Cout=F_, scale=self._grad_scale)
+        self._reduce_bucket("conv1")
         dx = None
         if need_input_grad:
             dxn = _empty(N, H, W, C_, device=dev)
@@ -418,6 +467,7 @@ class GeneratorEngine:
             else:
                 dx = _empty(N, C_, H, W, device=dev)
                 L.nhwc_to_nchw(View(dxn), dx, N, C_, H, W)
+        self._finish_reduce()
         return dx, grads
 
 
