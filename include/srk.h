@@ -107,6 +107,12 @@ typedef struct srk_wgrad_args {
 int srk_conv3x3_wgrad(const srk_wgrad_args* a, void* stream);
 int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* a, size_t* bytes);
 
+/* n (<= 8) weight-gradient problems that share N,H,W,OH,OW,stride,dy_mode in ONE pair of launches (the five
+ * convs of a DenseResidualBlock, models.py:24-28: their 15 (64 cout x 64 cin) chunks fill the chip with few
+ * pixel-splits, so the partial-sum traffic stays small).  The workspace of args[0] is used for all. */
+int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void* stream);
+int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_t* bytes);
+
 /* Weight packing (OIHW fp32 -> MFMA-fragment order).  One launch packs a whole table.
  * Destination layout for a conv with K input channels and M outputs, Mp = round_up(M, 32):
  *   dst[q][tap][h][m][e]  (q = K/8 chunks, tap = 3r+s, h in {0,1}, e in 0..3)

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libsrk.so")
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_pack_plan", "srk_pack_weights",
+    "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
     "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_strerror", "srk_version",
 ]
@@ -77,6 +78,8 @@ def lib():
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), _fp]
         L.srk_conv3x3_wgrad_workspace.argtypes = [C.POINTER(WgradArgs), C.POINTER(C.c_size_t)]
+        L.srk_conv3x3_wgrad_batched.argtypes = [C.POINTER(WgradArgs), C.c_int, _fp]
+        L.srk_conv3x3_wgrad_batched_workspace.argtypes = [C.POINTER(WgradArgs), C.c_int, C.POINTER(C.c_size_t)]
         L.srk_pack_plan.argtypes = [C.POINTER(PackEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_pack_weights.argtypes = [_fp, C.c_int, C.c_int64, _fp]
         for name in ("srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd"):
@@ -212,6 +215,33 @@ def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, C
         e1.record()
         return
     check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
+
+
+def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLAIN):
+    """problems: list of dicts(x=View, dy=View, dw=Tensor, db=Tensor|None, Cin, Cout, scale, accumulate, in_slope)."""
+    n = len(problems)
+    arr = (WgradArgs * n)()
+    flops = 0.0
+    for a, p in zip(arr, problems):
+        a.N, a.H, a.W, a.OH, a.OW, a.stride, a.dy_mode = N, H, W, OH, OW, stride, dy_mode
+        a.Cin, a.Cout = p["Cin"], p["Cout"]
+        x, dy = p["x"], p["dy"]
+        a.x, a.x_ldc, a.x_coff, a.in_slope = x.t.data_ptr(), x.ldc, x.coff, p.get("in_slope", 1.0)
+        a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff
+        a.dw, a.db = p["dw"].data_ptr(), ptr(p.get("db"))
+        a.scale, a.accumulate = p.get("scale", 1.0), int(p.get("accumulate", False))
+        flops += 2.0 * N * OH * OW * a.Cout * a.Cin * 9
+    nbytes = C.c_size_t(0)
+    check(lib().srk_conv3x3_wgrad_batched_workspace(arr, n, C.byref(nbytes)), "srk_conv3x3_wgrad_batched_workspace")
+    ws = _workspace(nbytes.value, problems[0]["x"].t.device)
+    arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
+    if KernelTimer.active:
+        e0, e1 = KernelTimer.bracket(f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce", flops)
+        e0.record()
+        check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
+        e1.record()
+        return
+    check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
 
 
 def packed_floats(K: int, M: int) -> int:

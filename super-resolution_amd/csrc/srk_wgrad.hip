@@ -1,15 +1,20 @@
 // srk_wgrad.hip -- weight/bias gradient of the 3x3 / pad-1 convolution for gfx950, fp32.
 //
-//   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]
+//   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * lrelu_in(X[n, S*oh+r-1, S*ow+s-1, c])
 //
 // GEMM view: M = 64 output channels, N = 64 input channels (x 9 taps), K = pixels.  A workgroup owns one
-// (64 cout) x (64 cin) x 9-tap block of dW and a contiguous range of pixel tiles; wave (a,b) keeps the nine
-// 32x32 tiles dW[32a.., 32b.., tap] in 144 accumulator registers for the whole range, so the pixel
+// (64 cout) x (64 cin) x 9-tap block of dW ("chunk") and a contiguous range of pixel tiles; wave (a,b) keeps
+// the nine 32x32 tiles dW[32a.., 32b.., tap] in 144 accumulator registers for the whole range, so the pixel
 // reduction never leaves registers inside a workgroup.  Per pixel tile the DY tile [px][64] and the X halo
 // [(rows+2)x(cols+2)][64] are staged once in LDS; the nine taps are nine shifted ds_read_b32 streams of
-// the same halo (v_mfma_f32_32x32x2_f32: lane (i, h) supplies pixel 2kk+h).  Partial blocks of the P
-// pixel-splits go to a caller workspace and are summed in fixed order by wgrad_reduce (deterministic,
-// no float atomics), which also writes the canonical OIHW layout and undoes the PixelShuffle packing.
+// the same halo (v_mfma_f32_32x32x2_f32: lane (i, h) supplies pixel 2kk+h).
+//
+// Several problems that share the pixel geometry are BATCHED into one launch (grid.y enumerates the chunks
+// of all problems): the five convs of a DenseResidualBlock give 15 chunks, so ~34 pixel-splits already fill
+// the chip and the partial-sum traffic stays a few percent of the MFMA time.  The P partial blocks go to a
+// caller workspace and are summed in fixed order by wgrad_reduce (deterministic, no float atomics), which
+// transposes through LDS so that the canonical OIHW rows are written coalesced, undoes the PixelShuffle
+// packing and applies scale / accumulate.
 //
 // Mirrors the autograd weight/bias gradient of nn.Conv2d at /root/reference/models.py:19,63,67,87,97,99,
 // 142,144,168.
@@ -18,6 +23,9 @@
 namespace {
 
 constexpr int WTW = 16;
+constexpr int MAX_PROB = 8;
+constexpr int MAX_CHUNK = 64;
+
 template <int S> struct WGeo {
   static constexpr int TH = (S == 1) ? 4 : 2;
   static constexpr int TP = TH * WTW;              // pixels per tile
@@ -26,27 +34,23 @@ template <int S> struct WGeo {
   static constexpr int NHP = IH * IW;
 };
 
-struct WPlan { int P, tpb, tilesH, tilesW, total_tiles, nCy, nCz; };
+struct WProb {
+  const float* x; const float* dy; float* dw; float* db;
+  int x_ldc, x_coff, dy_ldc, dy_coff, Cin, Cout, accumulate;
+  float in_slope, scale;
+};
 
-template <int S>
-WPlan make_plan(const srk_wgrad_args& a) {
-  using G = WGeo<S>;
-  WPlan p;
-  p.tilesW = srk_div_up(a.OW, WTW);
-  p.tilesH = srk_div_up(a.OH, G::TH);
-  p.total_tiles = a.N * p.tilesH * p.tilesW;
-  p.nCy = srk_div_up(a.Cin, 64);
-  p.nCz = srk_div_up(a.Cout, 64);
-  int target = 512 / (p.nCy * p.nCz);
-  if (target < 1) target = 1;
-  int P = p.total_tiles < target ? p.total_tiles : target;
-  p.tpb = srk_div_up(p.total_tiles, P);
-  p.P = srk_div_up(p.total_tiles, p.tpb);
-  return p;
-}
+struct WBatch {
+  int N, H, W, OH, OW;
+  int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode;
+  WProb prob[MAX_PROB];
+  unsigned char c_prob[MAX_CHUNK], c_cy[MAX_CHUNK], c_cz[MAX_CHUNK];
+};
+
+constexpr size_t CHUNK_FLOATS = 9 * 64 * 64;
 
 template <int S, int DYMODE, bool VEC>
-__global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgrad_args a, const WPlan pl, float* part, float* pbias) {
+__global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch B, float* part, float* pbias) {
   using G = WGeo<S>;
   __shared__ float smem[G::TP * 64 + G::NHP * 64];
   float* dys = smem;                 // [TP][64]
@@ -55,11 +59,14 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int hl = lane >> 5, l32 = lane & 31;
   const int wa = wv & 1, wb = wv >> 1;
-  const int p = blockIdx.x, cy = blockIdx.y, cz = blockIdx.z;
+  const int p = blockIdx.x, chunk = blockIdx.y;
+  const WProb& a = B.prob[B.c_prob[chunk]];
+  const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
   const int cin0 = cy * 64, cout0 = cz * 64;
   const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
-  const bool do_bias = (pbias != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
+  const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
   const int Cps = a.Cout >> 2;
+  const float in_slope = a.in_slope;
 
   f32x16 acc[9];
 #pragma unroll
@@ -68,14 +75,14 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
-  const int t_begin = p * pl.tpb;
-  int t_end = t_begin + pl.tpb;
-  if (t_end > pl.total_tiles) t_end = pl.total_tiles;
+  const int t_begin = p * B.tpb;
+  int t_end = t_begin + B.tpb;
+  if (t_end > B.total_tiles) t_end = B.total_tiles;
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     int tt = tile;
-    const int tx = tt % pl.tilesW; tt /= pl.tilesW;
-    const int ty = tt % pl.tilesH; tt /= pl.tilesH;
+    const int tx = tt % B.tilesW; tt /= B.tilesW;
+    const int ty = tt % B.tilesH; tt /= B.tilesH;
     const int n = tt;
     const int oh0 = ty * G::TH, ow0 = tx * WTW;
     const int ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;
@@ -86,13 +93,13 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
       const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
       const int co = cout0 + 4 * c4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oh < a.OH && ow < a.OW && co < a.Cout) {
+      if (oh < B.OH && ow < B.OW && co < a.Cout) {
         const float* src;
         if (DYMODE == SRK_IN_UNSHUFFLE) {
           const int ij = co / Cps, c = co - ij * Cps;
-          src = a.dy + ((long)(n * 2 * a.OH + 2 * oh + (ij >> 1)) * (2 * a.OW) + 2 * ow + (ij & 1)) * a.dy_ldc + a.dy_coff + c;
+          src = a.dy + ((long)(n * 2 * B.OH + 2 * oh + (ij >> 1)) * (2 * B.OW) + 2 * ow + (ij & 1)) * a.dy_ldc + a.dy_coff + c;
         } else {
-          src = a.dy + ((long)(n * a.OH + oh) * a.OW + ow) * a.dy_ldc + a.dy_coff + co;
+          src = a.dy + ((long)(n * B.OH + oh) * B.OW + ow) * a.dy_ldc + a.dy_coff + co;
         }
         if (VEC) {
           v = *reinterpret_cast<const float4*>(src);
@@ -112,8 +119,8 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
       const int ih = ih0 + hy, iw = iw0 + hx;
       const int ci = cin0 + 4 * c4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ih >= 0 && iw >= 0 && ih < a.H && iw < a.W && ci < a.Cin) {
-        const float* src = a.x + ((long)(n * a.H + ih) * a.W + iw) * a.x_ldc + a.x_coff + ci;
+      if (ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
+        const float* src = a.x + ((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff + ci;
         if (VEC) {
           v = *reinterpret_cast<const float4*>(src);
         } else {
@@ -123,9 +130,9 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
           if (ci + 3 < a.Cin) v.w = src[3];
         }
       }
-      if (a.in_slope != 1.f) {
-        v.x = v.x > 0.f ? v.x : v.x * a.in_slope; v.y = v.y > 0.f ? v.y : v.y * a.in_slope;
-        v.z = v.z > 0.f ? v.z : v.z * a.in_slope; v.w = v.w > 0.f ? v.w : v.w * a.in_slope;
+      if (in_slope != 1.f) {
+        v.x = v.x > 0.f ? v.x : v.x * in_slope; v.y = v.y > 0.f ? v.y : v.y * in_slope;
+        v.z = v.z > 0.f ? v.z : v.z * in_slope; v.w = v.w > 0.f ? v.w : v.w * in_slope;
       }
       reinterpret_cast<float4*>(xs)[idx] = v;
     }
@@ -150,9 +157,9 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
     __syncthreads();
   }
 
-  // ---- write partial block: part[p][cz][cy][tap][64 cout][64 cin]
+  // ---- write partial block: part[p][chunk][tap][64 cout][64 cin]
   if (active) {
-    float* dst = part + (((long)p * pl.nCz + cz) * pl.nCy + cy) * (9 * 64 * 64);
+    float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -163,69 +170,89 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const srk_wgr
   }
   if (do_bias) {
     const float tot = bsum + __shfl_xor(bsum, 32);
-    if (hl == 0) pbias[((long)p * pl.nCz + cz) * 64 + 32 * wa + l32] = tot;
+    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
 }
 
-// one thread per (o, c, tap); sums the P partial blocks in fixed order
-__global__ void wgrad_reduce_kernel(const srk_wgrad_args a, const WPlan pl, const float* part, const float* pbias) {
-  const long total = (long)pl.nCz * pl.nCy * 9 * 64 * 64;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < total) {
-    long t = gid;
-    const int cl = t & 63; t >>= 6;
-    const int ol = t & 63; t >>= 6;
-    const int tap = t % 9; t /= 9;
-    const int cy = t % pl.nCy; t /= pl.nCy;
-    const int cz = (int)t;
-    const int o = cz * 64 + ol, c = cy * 64 + cl;
-    if (o < a.Cout && c < a.Cin) {
-      const long stride = (long)pl.nCz * pl.nCy * 9 * 64 * 64;
-      const float* src = part + (((long)cz * pl.nCy + cy) * 9 + tap) * 4096 + ol * 64 + cl;
-      float s = 0.f;
-      for (int p = 0; p < pl.P; ++p) s += src[p * stride];
-      int os = o;
-      if (a.dy_mode == SRK_IN_UNSHUFFLE) { const int Cps = a.Cout >> 2; os = 4 * (o % Cps) + o / Cps; }
-      float* d = a.dw + ((long)os * a.Cin + c) * 9 + tap;
-      *d = a.accumulate ? (*d + a.scale * s) : a.scale * s;
+// grid (64 local cout rows, n_chunks), 576 threads = (tap, 64 cin).  Sums the P partials in fixed order,
+// transposes [tap][c] -> [c][tap] through LDS and writes one contiguous OIHW row segment dW[o][c0..c0+63][0..8].
+__global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias) {
+  __shared__ float row[576];
+  const int chunk = blockIdx.y, ol = blockIdx.x, t = threadIdx.x;
+  const WProb& a = B.prob[B.c_prob[chunk]];
+  const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
+  const int o = cz * 64 + ol;
+  if (o >= a.Cout) return;
+  const int tap = t >> 6, cl = t & 63;
+  const size_t stride = (size_t)B.n_chunks * CHUNK_FLOATS;
+  const float* src = part + (size_t)chunk * CHUNK_FLOATS + (tap * 64 + ol) * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (cy * 64 + cl < a.Cin) {     // partial blocks of padding waves are never written
+    int p = 0;
+    for (; p + 4 <= B.P; p += 4) {
+      s0 += src[(size_t)p * stride];
+      s1 += src[(size_t)(p + 1) * stride];
+      s2 += src[(size_t)(p + 2) * stride];
+      s3 += src[(size_t)(p + 3) * stride];
     }
+    for (; p < B.P; ++p) s0 += src[(size_t)p * stride];
   }
-  if (a.db && gid < a.Cout) {
-    const int o = (int)gid;
+  row[cl * 9 + tap] = a.scale * ((s0 + s1) + (s2 + s3));
+  __syncthreads();
+  int os = o;
+  if (B.dy_mode == SRK_IN_UNSHUFFLE) { const int Cps = a.Cout >> 2; os = 4 * (o % Cps) + o / Cps; }
+  const int c = cy * 64 + t / 9;
+  if (c < a.Cin) {
+    float* d = a.dw + ((size_t)os * a.Cin + cy * 64) * 9 + t;
+    *d = a.accumulate ? (*d + row[t]) : row[t];
+  }
+  if (a.db && cy == 0 && t == 0) {
     float s = 0.f;
-    for (int p = 0; p < pl.P; ++p) s += pbias[(long)p * pl.nCz * 64 + o];
-    int os = o;
-    if (a.dy_mode == SRK_IN_UNSHUFFLE) { const int Cps = a.Cout >> 2; os = 4 * (o % Cps) + o / Cps; }
+    for (int q = 0; q < B.P; ++q) s += pbias[((size_t)q * B.n_chunks + chunk) * 64 + ol];
     a.db[os] = a.accumulate ? (a.db[os] + a.scale * s) : a.scale * s;
   }
 }
 
-size_t ws_bytes(const WPlan& pl) {
-  return ((size_t)pl.P * pl.nCz * pl.nCy * 9 * 64 * 64 + (size_t)pl.P * pl.nCz * 64) * sizeof(float);
-}
-
-template <int S, int DYMODE, bool VEC>
-int launch(const srk_wgrad_args& a, hipStream_t st) {
-  const WPlan pl = make_plan<S>(a);
-  if (!a.workspace || a.workspace_bytes < ws_bytes(pl)) return SRK_ERR_WORKSPACE;
-  float* part = (float*)a.workspace;
-  float* pbias = part + (size_t)pl.P * pl.nCz * pl.nCy * 9 * 64 * 64;
-  dim3 grid(pl.P, pl.nCy, pl.nCz);
-  hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC>), grid, dim3(SRK_THREADS), 0, st, a, pl, part, a.db ? pbias : nullptr);
-  SRK_CHECK_LAUNCH();
-  const long total = (long)pl.nCz * pl.nCy * 9 * 64 * 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, pl, part, pbias);
-  SRK_CHECK_LAUNCH();
+int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
+  if (!args || n <= 0 || n > MAX_PROB) return SRK_ERR_BAD_ARG;
+  const srk_wgrad_args& a0 = args[0];
+  if (a0.stride != 1 && a0.stride != 2) return SRK_ERR_UNSUPPORTED;
+  if (a0.dy_mode != SRK_IN_PLAIN && a0.dy_mode != SRK_IN_UNSHUFFLE) return SRK_ERR_UNSUPPORTED;
+  if (a0.N <= 0 || a0.H <= 0 || a0.W <= 0 || a0.OH <= 0 || a0.OW <= 0) return SRK_ERR_BAD_ARG;
+  B.N = a0.N; B.H = a0.H; B.W = a0.W; B.OH = a0.OH; B.OW = a0.OW; B.dy_mode = a0.dy_mode; B.n_prob = n;
+  int nc = 0;
+  for (int i = 0; i < n; ++i) {
+    const srk_wgrad_args& a = args[i];
+    if (!a.x || !a.dy || !a.dw || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
+    if (a.N != a0.N || a.H != a0.H || a.W != a0.W || a.OH != a0.OH || a.OW != a0.OW || a.stride != a0.stride || a.dy_mode != a0.dy_mode)
+      return SRK_ERR_UNSUPPORTED;
+    if (a.dy_mode == SRK_IN_UNSHUFFLE && (a.stride != 1 || (a.Cout & 3) || ((a.Cout >> 2) & 3))) return SRK_ERR_UNSUPPORTED;
+    WProb& p = B.prob[i];
+    p.x = a.x; p.dy = a.dy; p.dw = a.dw; p.db = a.db;
+    p.x_ldc = a.x_ldc; p.x_coff = a.x_coff; p.dy_ldc = a.dy_ldc; p.dy_coff = a.dy_coff;
+    p.Cin = a.Cin; p.Cout = a.Cout; p.accumulate = a.accumulate; p.in_slope = a.in_slope; p.scale = a.scale;
+    for (int cz = 0; cz < srk_div_up(a.Cout, 64); ++cz)
+      for (int cy = 0; cy < srk_div_up(a.Cin, 64); ++cy) {
+        if (nc >= MAX_CHUNK) return SRK_ERR_UNSUPPORTED;
+        B.c_prob[nc] = (unsigned char)i; B.c_cy[nc] = (unsigned char)cy; B.c_cz[nc] = (unsigned char)cz;
+        ++nc;
+      }
+  }
+  B.n_chunks = nc;
+  const int TH = a0.stride == 1 ? WGeo<1>::TH : WGeo<2>::TH;
+  B.tilesW = srk_div_up(a0.OW, WTW);
+  B.tilesH = srk_div_up(a0.OH, TH);
+  B.total_tiles = a0.N * B.tilesH * B.tilesW;
+  int target = 512 / nc;
+  if (target < 1) target = 1;
+  int P = B.total_tiles < target ? B.total_tiles : target;
+  B.tpb = srk_div_up(B.total_tiles, P);
+  B.P = srk_div_up(B.total_tiles, B.tpb);
   return SRK_OK;
 }
 
-int validate(const srk_wgrad_args& a) {
-  if (!a.x || !a.dy || !a.dw) return SRK_ERR_BAD_ARG;
-  if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
-  if (a.stride != 1 && a.stride != 2) return SRK_ERR_UNSUPPORTED;
-  if (a.dy_mode != SRK_IN_PLAIN && a.dy_mode != SRK_IN_UNSHUFFLE) return SRK_ERR_UNSUPPORTED;
-  if (a.dy_mode == SRK_IN_UNSHUFFLE && (a.stride != 1 || (a.Cout & 3) || ((a.Cout >> 2) & 3))) return SRK_ERR_UNSUPPORTED;
-  return SRK_OK;
+size_t ws_bytes(const WBatch& B) {
+  return ((size_t)B.P * B.n_chunks * CHUNK_FLOATS + (size_t)B.P * B.n_chunks * 64) * sizeof(float);
 }
 
 bool is_vec(const srk_wgrad_args& a) {
@@ -233,27 +260,50 @@ bool is_vec(const srk_wgrad_args& a) {
          (a.dy_coff % 4 == 0) && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
 }
 
-}  // namespace
-
-extern "C" int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* pa, size_t* bytes) {
-  if (!pa || !bytes) return SRK_ERR_BAD_ARG;
-  int rc = validate(*pa);
-  if (rc) return rc;
-  *bytes = pa->stride == 1 ? ws_bytes(make_plan<1>(*pa)) : ws_bytes(make_plan<2>(*pa));
+template <int S, int DYMODE, bool VEC>
+int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
+  dim3 grid(B.P, B.n_chunks);
+  hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+  SRK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
+  SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
 
-extern "C" int srk_conv3x3_wgrad(const srk_wgrad_args* pa, void* stream) {
-  if (!pa) return SRK_ERR_BAD_ARG;
-  const srk_wgrad_args& a = *pa;
-  int rc = validate(a);
+}  // namespace
+
+extern "C" int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_t* bytes) {
+  if (!bytes) return SRK_ERR_BAD_ARG;
+  WBatch B;
+  int rc = build_batch(args, n, B);
   if (rc) return rc;
+  *bytes = ws_bytes(B);
+  return SRK_OK;
+}
+
+extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void* stream) {
+  WBatch B;
+  int rc = build_batch(args, n, B);
+  if (rc) return rc;
+  const srk_wgrad_args& a0 = args[0];
+  if (!a0.workspace || a0.workspace_bytes < ws_bytes(B)) return SRK_ERR_WORKSPACE;
+  float* part = (float*)a0.workspace;
+  float* pbias = part + (size_t)B.P * B.n_chunks * CHUNK_FLOATS;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = is_vec(a);
-  if (a.dy_mode == SRK_IN_UNSHUFFLE) {
+  bool vec = true;
+  for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
+  if (a0.dy_mode == SRK_IN_UNSHUFFLE) {
     if (!vec) return SRK_ERR_ALIGNMENT;
-    return launch<1, SRK_IN_UNSHUFFLE, true>(a, st);
+    return launch<1, SRK_IN_UNSHUFFLE, true>(B, part, pbias, st);
   }
-  if (a.stride == 1) return vec ? launch<1, SRK_IN_PLAIN, true>(a, st) : launch<1, SRK_IN_PLAIN, false>(a, st);
-  return vec ? launch<2, SRK_IN_PLAIN, true>(a, st) : launch<2, SRK_IN_PLAIN, false>(a, st);
+  if (a0.stride == 1) return vec ? launch<1, SRK_IN_PLAIN, true>(B, part, pbias, st) : launch<1, SRK_IN_PLAIN, false>(B, part, pbias, st);
+  return vec ? launch<2, SRK_IN_PLAIN, true>(B, part, pbias, st) : launch<2, SRK_IN_PLAIN, false>(B, part, pbias, st);
+}
+
+extern "C" int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* pa, size_t* bytes) {
+  return srk_conv3x3_wgrad_batched_workspace(pa, 1, bytes);
+}
+
+extern "C" int srk_conv3x3_wgrad(const srk_wgrad_args* pa, void* stream) {
+  return srk_conv3x3_wgrad_batched(pa, 1, stream);
 }

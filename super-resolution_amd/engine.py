@@ -244,12 +244,14 @@ class GeneratorEngine:
                       mask=View(D, m * F_, F_), mask_slope=G_SLOPE)
         L.conv3x3(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
                   r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)
-        # weight gradients: conv k reads D[0:kF), its dy is E slice (5-k) (k=5: slice 0 scaled by s5)
+        # weight gradients: conv k reads D[0:kF), its dy is E slice (5-k) (k=5: slice 0 scaled by s5).
+        # One batched launch for the five convs (15 chunks of 64x64x9).
+        probs = []
         for k in range(1, 6):
             conv = getattr(d, f"b{k}")[0]
-            dw, db = grads[conv.weight], grads[conv.bias]
-            L.conv3x3_wgrad(View(D, 0, k * F_), View(E, (5 - k) * F_, F_), dw, db, N=N, H=H, W=W, OH=H, OW=W,
-                            Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0) * self._grad_scale)
+            probs.append(dict(x=View(D, 0, k * F_), dy=View(E, (5 - k) * F_, F_), dw=grads[conv.weight], db=grads[conv.bias],
+                              Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0) * self._grad_scale))
+        L.conv3x3_wgrad_batched(probs, N=N, H=H, W=W, OH=H, OW=W)
 
     def _rrdb_chain_forward(self, rrdbs, packs, x0: torch.Tensor, geo, save: bool):
         """Runs a chain of RRDBs.  x0: dense buffer [N,H,W,5F] whose slice 0 already holds the chain input.
