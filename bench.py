@@ -57,7 +57,8 @@ def cpu_baseline(res_blocks, workload):
     on a bounded sample; baseline only."""
     from oracle import esrgan_oracle as O
     n = 2
-    cores = torch.get_num_threads()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
     params = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999))

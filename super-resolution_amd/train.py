@@ -2,38 +2,101 @@
 
 ``Stepper`` owns the replicas (generator, discriminators, Adam states) of ONE rank and runs one iteration:
   * ``g_only``: the warm-up iteration, esrgan.py:416-439 -- ``L1(G(lr), hr)``, backward, ``optimizer_G.step()``
-  * ``gan``   : G phase (esrgan.py:457-555) + D phase (esrgan.py:561-626) at the default flags
-Data parallelism is one process per GPU; gradients are averaged with RCCL all-reduce (``torch.distributed``
-backend "nccl"), bucketed per RRDB and launched while the backward convolutions are still running.
+  * ``gan``   : G phase (esrgan.py:457-555) + D phase (esrgan.py:561-626) at the reference's default flags
+                (relativistic average BCE, hr/lr pixel terms, both "views" def/pow -> two discriminators,
+                gradient penalty lambda_reg, d_threshold gate)
+Data parallelism is one process per GPU; weight gradients are averaged with RCCL all-reduce
+(``torch.distributed`` backend "nccl"): the generator's are bucketed per RRDB and launched while the backward
+convolutions are still running (engine.py), the discriminators' (0.36 MB each) go as one flat buffer.
+With ``exact_dp`` the batch-coupled statistics of the loss (relativistic means, batch-mean
+image of the pixel loss, the d_threshold decision) are exchanged too, so N ranks x B images reproduce the
+single-process step on N*B images.
 """
+import math
+
 import torch
 import torch.nn as nn
 
 from . import models
 
+EPS = 1e-7   # esrgan.py:319
+
+
+class _AllReduceMean(torch.autograd.Function):
+    """y = mean over ranks of x.  d(loss_total)/dx = mean over ranks of dy (loss_total = mean of rank losses)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import torch.distributed as dist
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        return y / dist.get_world_size()
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g / dist.get_world_size()
+
 
 class Stepper:
     def __init__(self, workload="g_only", res_blocks=23, device=None, hr=256, factor=4, distributed=False, channels=1,
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
-                 lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0):
-        import math
+                 lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
+                 exact_dp=True, hr_shape=None):
         self.workload = workload
         self.device = device
         self.distributed = distributed
+        self.exact_dp = exact_dp and distributed
         self.factor = factor
+        self.lambdas = tuple(lambdas)
+        self.lambda_hr, self.lambda_adv, self.lambda_lr, self.lambda_reg = lambda_hr, lambda_adv, lambda_lr, lambda_reg
+        self.d_threshold = d_threshold
+        self.scaling_power = scaling_power
+        hr_shape = hr_shape or (hr, hr)
         self.generator = models.GeneratorRRDB(channels, filters=filters, num_res_blocks=res_blocks,
-                                              num_upsample=int(math.log2(factor)), res_scale=res_scale).to(device)
+                                              num_upsample=int(math.log2(factor)), res_scale=res_scale,
+                                              power=scaling_power).to(device)
         self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=betas, fused=True)
         self.criterion_pixel = nn.L1Loss()
+        self.criterion_GAN = nn.BCEWithLogitsLoss()
+        self.pool = models.SumPool2d(factor)
+        self.discriminators, self.optimizer_D = {}, {}
+        if workload == "gan":
+            for k in range(2):
+                if self.lambdas[k] > 0:
+                    D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
+                    self.discriminators[k] = D
+                    self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr, betas=betas, fused=True)
         if distributed:
             self.generator._engine.enable_grad_sync()
         self.last = {}
 
+    # ------------------------------------------------------------------ helpers
+    def _gmean(self, t):
+        """Batch statistic that the reference takes over the whole batch: mean over ranks of the local value."""
+        return _AllReduceMean.apply(t) if self.exact_dp else t
+
+    def _sync_grads(self, module):
+        if not self.distributed:
+            return
+        import torch.distributed as dist
+        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
     def step(self, imgs_lr, imgs_hr):
         if self.workload == "g_only":
             return self._warmup_step(imgs_lr, imgs_hr)
-        raise NotImplementedError(self.workload)
+        return self._gan_step(imgs_lr, imgs_hr)
 
+    # ------------------------------------------------------------------ warm-up iteration
     def _warmup_step(self, imgs_lr, imgs_hr):
         """esrgan.py:416-427."""
         self.optimizer_G.zero_grad(set_to_none=True)
@@ -42,4 +105,86 @@ class Stepper:
         loss_pixel.backward()
         self.optimizer_G.step()
         self.last = {"g_loss": loss_pixel.detach()}
+        return self.last
+
+    # ------------------------------------------------------------------ full GAN iteration
+    def g_phase_loss(self, imgs_lr, imgs_hr):
+        """esrgan.py:466-552 at the default flags.  Returns (loss_G, generated list, ground_truth list, parts)."""
+        p = self.scaling_power
+        generated = [self.generator(imgs_lr), self.generator.srs]
+        ground_truth = [imgs_hr, imgs_hr ** p]
+        gen_lr = self.pool(generated[0])
+        generated_lr = [gen_lr, gen_lr ** p]
+        ground_truth_lr = [imgs_lr, imgs_lr ** p]
+        loss_G = torch.zeros(1, device=imgs_lr.device)
+        parts = {}
+        for k in range(2):
+            if self.lambdas[k] <= 0:
+                continue
+            D = self.discriminators[k]
+            loss_pixel = self.criterion_pixel(self._gmean(generated[k].mean(0))[None, ...], self._gmean(ground_truth[k].mean(0))[None, ...])
+            loss_lr_pixel = self.criterion_pixel(generated_lr[k], ground_truth_lr[k])
+            # gradients deposited on D's weights here are discarded by optimizer_D.zero_grad() (esrgan.py:568):
+            # do not compute them
+            for q in D.parameters():
+                q.requires_grad_(False)
+            with torch.no_grad():
+                pred_real = D(ground_truth[k], ground_truth_lr[k])
+            pred_fake = D(generated[k], generated_lr[k])
+            for q in D.parameters():
+                q.requires_grad_(True)
+            valid = torch.ones_like(pred_real)
+            fake = torch.zeros_like(pred_real)
+            loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
+                             self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
+            tot = self.lambda_hr * loss_pixel + self.lambda_adv * loss_GAN + self.lambda_lr * loss_lr_pixel
+            loss_G = loss_G + self.lambdas[k] * tot
+            parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach(), tot=tot.detach())
+        return loss_G, generated, ground_truth, parts
+
+    def d_phase_loss(self, k, gt, gen_detached, epsilon=None):
+        """esrgan.py:569-606 for discriminator k.  ``epsilon``: (B,1,1,1) interpolation factors or None -> drawn here."""
+        D = self.discriminators[k]
+        pred_real = D(gt, None)
+        pred_fake = D(gen_detached, None)
+        valid = torch.ones_like(pred_real)
+        fake = torch.zeros_like(pred_real)
+        loss_real = self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), valid)
+        loss_fake = self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), fake)
+        loss_D = (loss_real + loss_fake) / 2
+        gp = None
+        if self.lambda_reg > 0:
+            B = gt.shape[0]
+            if epsilon is None:
+                epsilon = torch.rand(B, 1, 1, 1, device=gt.device)
+            interpolation = epsilon * gt + (1 - epsilon) * gen_detached
+            interpolation.requires_grad = True
+            pred_interpolation = D(interpolation, None)
+            gradients = torch.autograd.grad(outputs=pred_interpolation, inputs=interpolation, grad_outputs=valid,
+                                            create_graph=True, retain_graph=True, only_inputs=True)[0]
+            gradients = gradients.view(B, -1)
+            gp = ((gradients.norm(2, dim=1) - 1) ** 2).mean() * self.lambda_reg / 2
+            loss_D = loss_D + gp
+        return loss_D, gp
+
+    def _gan_step(self, imgs_lr, imgs_hr, epsilons=None):
+        # ---- generator (esrgan.py:416,457-555)
+        self.optimizer_G.zero_grad(set_to_none=True)
+        loss_G, generated, ground_truth, parts = self.g_phase_loss(imgs_lr, imgs_hr)
+        loss_G.backward()
+        self.optimizer_G.step()
+        # ---- discriminators (esrgan.py:561-626); they see the pre-update generator output
+        loss_D_tot = {}
+        for k, D in self.discriminators.items():
+            self.optimizer_D[k].zero_grad(set_to_none=True)
+            loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k])
+            loss_D.backward()
+            self._sync_grads(D)
+            gate = loss_D.detach()
+            if self.exact_dp:
+                gate = _AllReduceMean.apply(gate)      # every rank must take the same branch (SURVEY 8e)
+            if gate.item() > self.d_threshold:            # host sync, as in the reference (esrgan.py:623)
+                self.optimizer_D[k].step()
+            loss_D_tot[k] = loss_D.detach()
+        self.last = {"g_loss": loss_G.detach(), "d_loss": loss_D_tot, "parts": parts}
         return self.last
