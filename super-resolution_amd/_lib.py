@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrk.so")
+LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # override: diagnostic builds only
 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
@@ -154,7 +154,9 @@ def _conv_kernel_name(a) -> str:
     """Mirror of the dispatch in srk_conv.hip (srk_conv3x3)."""
     vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
     bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
-    return f"conv3x3_f32_kernel<{bn}, {a.stride}, {a.in_mode}, {'true' if vec else 'false'}>"
+    mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
+    dma = False   # the DMA staging variant is compiled out of the dispatch (slower on gfx950, see srk_conv.hip)
+    return f"conv3x3_f32_kernel<{bn}, {a.stride}, {a.in_mode}, {'true' if vec else 'false'}, {mt}, {'true' if dma else 'false'}>"
 
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,

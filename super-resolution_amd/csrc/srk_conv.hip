@@ -16,20 +16,45 @@
 // 63,67,86-90,97-99,126,142-145,168 (forward) and their autograd data-gradients.
 #include "srk_internal.h"
 
+#ifdef SRK_STAMP
+// diagnostic build only: per-workgroup phase stamps (s_memrealtime, 100 MHz) into a side buffer
+__device__ unsigned long long* g_srk_stamps = nullptr;
+extern "C" int srk_debug_set_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_srk_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#define SRK_STAMP_AT(k) do { if (threadIdx.x == 0 && g_srk_stamps) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SRK_CLOCK_AT(k) do { if (threadIdx.x == 0 && g_srk_stamps) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SRK_SEG_BEGIN() unsigned long long seg_t = __builtin_amdgcn_s_memtime(); unsigned long long seg_sum[6] = {0,0,0,0,0,0}
+#define SRK_SEG(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_sum[k] += t_ - seg_t; seg_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SRK_SEG_END() do { if (threadIdx.x == 0 && g_srk_stamps) for (int k_ = 0; k_ < 6; ++k_) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + k_] = seg_sum[k_]; } while (0)
+#else
+#define SRK_SEG_BEGIN() do { } while (0)
+#define SRK_SEG(k) do { } while (0)
+#define SRK_SEG_END() do { } while (0)
+#define SRK_CLOCK_AT(k) do { } while (0)
+#define SRK_STAMP_AT(k) do { } while (0)
+#endif
+
 namespace {
 
-template <int S>
+template <int S, int MT>
 struct Geo {
-  static constexpr int IH = (SRK_TH - 1) * S + 3;
+  static constexpr int TH = SRK_TH * MT;            // output rows per workgroup tile (8 or 16)
+  static constexpr int IH = (TH - 1) * S + 3;
   static constexpr int IW = (SRK_TW - 1) * S + 3;
   static constexpr int NHP = IH * IW;               // halo pixels
   static constexpr int NX4 = 2 * NHP;               // float4 per chunk (8 ch per pixel)
   static constexpr int NXS = (NX4 + SRK_THREADS - 1) / SRK_THREADS;  // slots per thread
 };
 
-template <int BN, int S, int MODE, bool VEC>
+// one 16-byte-per-lane global -> LDS DMA piece (buffer_load_dwordx4 ... lds); lds_dst is wave-uniform
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float4* lds_dst, unsigned voffset, unsigned soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
+template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
 __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv_args a) {
-  using G = Geo<S>;
+  using G = Geo<S, MT>;
   constexpr int NW4 = 18 * BN;                                  // weight float4 per chunk
   constexpr int NWS = (NW4 + SRK_THREADS - 1) / SRK_THREADS;
   constexpr int NXS = G::NXS;
@@ -38,6 +63,7 @@ __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv
   __shared__ float4 smem[2 * (G::NX4 + NW4)];
   constexpr int BUF4 = G::NX4 + NW4;   // buffer b: xs at smem + b*BUF4, ws right after it
 
+  SRK_STAMP_AT(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
@@ -45,12 +71,12 @@ __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv
   const int l32 = lane & 31;
 
   const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW;
-  const int tilesH = (a.OH + SRK_TH - 1) / SRK_TH;
+  const int tilesH = (a.OH + G::TH - 1) / G::TH;
   int bid = blockIdx.x;
   const int tx = bid % tilesW; bid /= tilesW;
   const int ty = bid % tilesH; bid /= tilesH;
   const int n = bid;
-  const int oh0 = ty * SRK_TH, ow0 = tx * SRK_TW;
+  const int oh0 = ty * G::TH, ow0 = tx * SRK_TW;
   const int n0 = blockIdx.y * BN;
   const int CoutP = (a.Cout + 31) & ~31;
   const int nq = (a.Cin + 7) >> 3;
@@ -81,140 +107,336 @@ __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv
     }
     xoff[u] = off; xin[u] = inb; xhalf[u] = half;
   }
+  // VEC path: branch-free staging through buffer descriptors (out-of-range lanes read 0).  The descriptor
+  // covers this image only (so byte offsets fit 32 bits); the chunk's channel offset goes in soffset.
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned xvo[NXS], wvo[NWS];
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const float* ximg = a.x + (long)n * img_elems;
+#pragma unroll
+  for (int u = 0; u < NXS; ++u) xvo[u] = xin[u] ? (unsigned)((xoff[u] - (long)n * img_elems) * 4) : OOB;
+#pragma unroll
+  for (int v = 0; v < NWS; ++v) {
+    const int idx = tid + v * SRK_THREADS;
+    const int th = idx / BN, co = idx - th * BN;
+    wvo[v] = (idx < NW4 && n0 + co < CoutP) ? (unsigned)((th * CoutP + n0 + co) * 16) : OOB;
+  }
+  const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
+  const unsigned wbytes = (unsigned)((long)nq * 18 * CoutP * 16);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
 
   float4 xr[NXS];
   float4 wr[NWS];
 
-  auto load_chunk = [&](int q) {
-    long cadd = 8 * q;
-    if (MODE == SRK_IN_UNSHUFFLE) {
-      const int c8 = 8 * q;
-      const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
-      cadd = (long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c;
-    }
-#pragma unroll
-    for (int u = 0; u < NXS; ++u) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xin[u]) {
-        const float* p = a.x + xoff[u] + cadd;
-        if (VEC) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          const int c = 8 * q + 4 * xhalf[u];
-          if (c + 0 < a.Cin) v.x = p[0];
-          if (c + 1 < a.Cin) v.y = p[1];
-          if (c + 2 < a.Cin) v.z = p[2];
-          if (c + 3 < a.Cin) v.w = p[3];
-        }
+  constexpr int NSLOT = NXS + NWS;              // staging work items per chunk, one 16-byte load/store each
+  // slot i < NXS: input halo float4 #i of this thread; else weight float4 #(i - NXS)
+  auto load_slot = [&](int i, int q) {
+    if (i < NXS) {
+      const int u = i;
+      long cadd = 8 * q;
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c8 = 8 * q;
+        const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+        cadd = (long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c;
       }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (VEC) {
+        const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvo[u], (unsigned)(cadd * 4), 0));
+        v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      } else if (xin[u]) {
+        const float* p = a.x + xoff[u] + cadd;
+        const int c = 8 * q + 4 * xhalf[u];
+        if (c + 0 < a.Cin) v.x = p[0];
+        if (c + 1 < a.Cin) v.y = p[1];
+        if (c + 2 < a.Cin) v.z = p[2];
+        if (c + 3 < a.Cin) v.w = p[3];
+      }
+      xr[u] = v;
+    } else {
+      const int v = i - NXS;
+      const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo[v], (unsigned)(q * 18 * CoutP * 16), 0));
+      wr[v] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+    }
+  };
+  auto store_slot = [&](int i, int b) {
+    if (i < NXS) {
+      const int u = i;
+      const int idx = tid + u * SRK_THREADS;
+      float4 v = xr[u];
       if (a.in_slope != 1.f) {
         v.x = v.x > 0.f ? v.x : v.x * a.in_slope; v.y = v.y > 0.f ? v.y : v.y * a.in_slope;
         v.z = v.z > 0.f ? v.z : v.z * a.in_slope; v.w = v.w > 0.f ? v.w : v.w * a.in_slope;
       }
-      xr[u] = v;
-    }
-    const float4* wq = reinterpret_cast<const float4*>(a.wp) + (long)q * 18 * CoutP;
-#pragma unroll
-    for (int v = 0; v < NWS; ++v) {
-      const int idx = tid + v * SRK_THREADS;
-      const int th = idx / BN, co = idx - th * BN;
-      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < NW4 && n0 + co < CoutP) w4 = wq[th * CoutP + n0 + co];
-      wr[v] = w4;
-    }
-  };
-  auto store_chunk = [&](int b) {
-#pragma unroll
-    for (int u = 0; u < NXS; ++u) {
-      const int idx = tid + u * SRK_THREADS;
-      if (idx < G::NX4) smem[b * BUF4 + idx] = xr[u];
-    }
-#pragma unroll
-    for (int v = 0; v < NWS; ++v) {
+      if (idx < G::NX4) smem[b * BUF4 + idx] = v;
+    } else {
+      const int v = i - NXS;
       const int idx = tid + v * SRK_THREADS;
       if (idx < NW4) smem[b * BUF4 + G::NX4 + idx] = wr[v];
     }
   };
-
-  f32x16 acc[NTN];
+  // DMA variant: the same slot goes global -> LDS directly (buffer_load ... lds: LDS address = wave-uniform base
+  // + lane*16, which is exactly the lane-linear [idx] layout used here; out-of-range lanes deliver 0).
+  auto dma_slot = [&](int i, int q, int b) {
+    if (i < NXS) {
+      const int u = i;
+      long cadd = 8 * q;
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c8 = 8 * q;
+        const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+        cadd = (long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c;
+      }
+      const int idx0 = wv * 64 + u * SRK_THREADS;                 // lane 0's float4 index
+      if (idx0 + lane < G::NX4)
+        dma16(xrsrc, smem + b * BUF4 + idx0, xvo[u], (unsigned)(cadd * 4));
+    } else {
+      const int v = i - NXS;
+      const int idx0 = wv * 64 + v * SRK_THREADS;
+      if (idx0 + lane < NW4)
+        dma16(wrsrc, smem + b * BUF4 + G::NX4 + idx0, wvo[v], (unsigned)(q * 18 * CoutP * 16));
+    }
+  };
+  auto load_chunk = [&](int q) {
 #pragma unroll
-  for (int t = 0; t < NTN; ++t)
+    for (int i = 0; i < NSLOT; ++i) load_slot(i, q);
+  };
+  auto store_chunk = [&](int b) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int i = 0; i < NSLOT; ++i) store_slot(i, b);
+  };
 
-  // A-fragment base: this lane's output pixel inside the tile (wave wv owns rows 2wv, 2wv+1)
+  f32x16 acc[MT][NTN];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  // A-fragment base: this lane's output pixel inside the tile.  Wave wv owns rows 2wv, 2wv+1 of every
+  // 8-row group m (pixel i of the 32x32 MFMA tile = row 2wv + (i>>4) + 8m, column i & 15).
   const int apy = 2 * wv + (l32 >> 4), apx = l32 & 15;
   const int abase = (apy * S) * G::IW + apx * S;
+  constexpr int AM = 8 * S * G::IW;          // halo-pixel offset between the wave's two M tiles
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int q = 0; q < nq; ++q) {
-    const int b = q & 1;
-    if (q + 1 < nq) load_chunk(q + 1);
-    const float4* xb = smem + b * BUF4;
-    const float4* wb = xb + G::NX4;
+  if constexpr (DMA) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, s = tap - 3 * r;
-      const float4 av = xb[(abase + r * G::IW + s) * 2 + hl];
+    for (int i = 0; i < NSLOT; ++i) dma_slot(i, 0, 0);
+    SRK_STAMP_AT(1);
+  } else {
+    load_chunk(0);
+    SRK_STAMP_AT(1);
+    store_chunk(0);
+  }
+  __syncthreads();
+  SRK_STAMP_AT(2);
+  SRK_CLOCK_AT(5);
+
+  // Fragment registers: fr[p] holds (A per M tile, B per N tile) of one tap; tap+1 is always in flight while
+  // tap's MFMAs issue.  The last tap of a chunk is issued AFTER the chunk's barrier, behind the first fragment
+  // reads of the next chunk, so neither the barrier nor the LDS latency behind it drains the matrix pipe.
+  float4 av[2][MT], bv[2][NTN];
+  auto ld_frag = [&](int p, int b, int tap) {
+    const int r = tap / 3, s = tap - 3 * r;
+    const float4* xb = smem + b * BUF4 + abase * 2 + hl;
+    const float4* wb = smem + b * BUF4 + G::NX4 + hl * BN + l32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av[p][m] = xb[(m * AM + r * G::IW + s) * 2];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) bv[p][t] = wb[tap * 2 * BN + t * 32];
+  };
+  // One k-step (4 accumulators x 1 MFMA each) of tap fragments fr[p]; k-step outermost so that consecutive
+  // MFMAs hit different accumulators.
+  auto mfma_kstep = [&](int p, int e) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NTN; ++t) {
-        const float4 bv = wb[(tap * 2 + hl) * BN + t * 32 + l32];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+        const float ae = e == 0 ? av[p][m].x : e == 1 ? av[p][m].y : e == 2 ? av[p][m].z : av[p][m].w;
+        const float be = e == 0 ? bv[p][t].x : e == 1 ? bv[p][t].y : e == 2 ? bv[p][t].z : bv[p][t].w;
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[m][t], 0, 0, 0);
+      }
+  };
+
+  // Staging is spread over the MFMA stream, ONE 16-byte global load (taps 0..) or LDS store (taps 4..) per
+  // k-step: issued as a burst, the 4 waves' 1-KB requests queue in the CU's memory pipe (~16 clk each) and
+  // stall the in-order waves for ~1000 clk per chunk; issued one at a time they hide behind the MFMAs.
+  constexpr int ST0 = 4;                          // first tap that carries LDS stores
+  static_assert(NSLOT <= 16, "staging slots must fit taps 0..3 / 4..7");
+  ld_frag(0, 0, 0);
+  SRK_SEG_BEGIN();
+  for (int q = 0; q < nq; ++q) {
+    const int b = q & 1;
+    const bool more = q + 1 < nq;
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) {
+      ld_frag((tap + 1) & 1, b, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);         // keep the next tap's ds_reads AHEAD of this tap's MFMAs
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mfma_kstep(tap & 1, e);
+        const int li = tap * 4 + e, si = (tap - ST0) * 4 + e;
+        if constexpr (DMA) {
+          if (more && li < NSLOT) { __builtin_amdgcn_sched_barrier(0); dma_slot(li, q + 1, b ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        } else {
+          if (more && tap < ST0 && li < NSLOT) { __builtin_amdgcn_sched_barrier(0); load_slot(li, q + 1); __builtin_amdgcn_sched_barrier(0); }
+          if (more && tap >= ST0 && si < NSLOT) { __builtin_amdgcn_sched_barrier(0); store_slot(si, b ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        }
       }
     }
-    if (q + 1 < nq) store_chunk(b ^ 1);
-    __syncthreads();
+    SRK_SEG(3);
+    __syncthreads();                             // buffer b fully consumed (tap 8 is in registers), b^1 visible
+    SRK_SEG(4);
+    if (more) ld_frag(1, b ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mfma_kstep(0, e);  // tap 8
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[0][m] = av[1][m];
+#pragma unroll
+      for (int t = 0; t < NTN; ++t) bv[0][t] = bv[1][t];
+    }
+    SRK_SEG(5);
   }
 
-  // ---- epilogue.  acc[t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl, channel = n0 + 32t + l32
+  SRK_SEG_END();
+  SRK_CLOCK_AT(6);
+  SRK_STAMP_AT(3);
+  // ---- epilogue.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of the M tile, channel = n0 + 32t + l32.
+  // Inside one M tile the lane's 16 registers are 2 rows x 8 columns {c, c+1, c+2, c+3, c+8, .., c+11} with
+  // c = 4*hl: every address is  base + (reg>>3)*row_stride + col(reg)*col_stride  (32-bit offsets from one
+  // 64-bit base per tensor), and interior tiles skip all bounds checks.
   const int Cps_out = a.Cout >> 2;
+  const bool interior = (oh0 + G::TH <= a.OH) && (ow0 + SRK_TW <= a.OW);
+  const int rowmul = a.ps_out ? 4 * a.OW : a.OW, colmul = a.ps_out ? 2 : 1;   // physical pixel steps per logical row/col
+  constexpr int NG = NTN * MT;
+  const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.mask != nullptr;
+  // 16-byte path: every tensor the epilogue touches is float4-addressable per pixel
+  const bool vec_out = ((a.Cout & 3) == 0) && (!a.ps_out || (Cps_out & 3) == 0) &&
+                       ((a.y_ldc | a.y_coff) & 3) == 0 && (((uintptr_t)a.y) & 15) == 0 &&
+                       (!a.bias || (((uintptr_t)a.bias) & 15) == 0) &&
+                       (!has_r1 || ((((a.r1_ldc | a.r1_coff) & 3) == 0) && (((uintptr_t)a.r1) & 15) == 0)) &&
+                       (!has_r2 || ((((a.r2_ldc | a.r2_coff) & 3) == 0) && (((uintptr_t)a.r2) & 15) == 0)) &&
+                       (!has_m || ((((a.m_ldc | a.m_coff) & 3) == 0) && (((uintptr_t)a.mask) & 15) == 0));
+  if (vec_out) {
+    // Transpose each 32 px x 32 ch accumulator tile through this wave's private 4 KB of LDS so that a lane
+    // owns 4 consecutive channels of one pixel: 16-byte loads/stores, 4x fewer store instructions (the
+    // store tail is issue-bound).  The main loop's last barrier has retired every other use of the LDS.
+    float* ls = reinterpret_cast<float*>(smem) + wv * 1024;
+    float4* ls4 = reinterpret_cast<float4*>(ls);
 #pragma unroll
-  for (int t = 0; t < NTN; ++t) {
-    const int co = n0 + t * 32 + l32;
-    if (co >= a.Cout) continue;
-    const float bz = a.bias ? a.bias[co] : 0.f;
-    int ch = co, pi = 0, pj = 0;
-    if (a.ps_out) { const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1; }
+    for (int g = 0; g < NG; ++g) {
+      const int t = g / MT, m = g % MT;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
-      const int oh = oh0 + 2 * wv + (i >> 4), ow = ow0 + (i & 15);
-      if (oh >= a.OH || ow >= a.OW) continue;
-      long pix;
-      if (a.ps_out) pix = ((long)(n * 2 * a.OH) + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj;
-      else pix = ((long)n * a.OH + oh) * a.OW + ow;
-      float v = a.alpha * (acc[t][reg] + bz);
-      if (a.r1) v += a.beta1 * a.r1[pix * a.r1_ldc + a.r1_coff + ch];
-      if (a.r2) v += a.beta2 * a.r2[pix * a.r2_ldc + a.r2_coff + ch];
-      v = v > 0.f ? v : v * a.slope;
-      if (a.mask) v *= (a.mask[pix * a.m_ldc + a.m_coff + ch] > 0.f ? 1.f : a.mask_slope);
-      a.y[pix * a.y_ldc + a.y_coff + ch] = v;
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+        ls[i * 32 + l32] = acc[m][t][reg];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = j * 64 + lane;
+        const int pl = idx >> 3, c4 = idx & 7;
+        const int oh = oh0 + 8 * m + 2 * wv + (pl >> 4), ow = ow0 + (pl & 15);
+        const int co = n0 + t * 32 + 4 * c4;
+        float4 v = ls4[idx];
+        if (co < a.Cout && (interior || (oh < a.OH && ow < a.OW))) {
+          int ch = co, pi = 0, pj = 0;
+          long pix;
+          if (a.ps_out) {
+            const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1;
+            pix = ((long)(n * 2 * a.OH) + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj;
+          } else {
+            pix = ((long)n * a.OH + oh) * a.OW + ow;
+          }
+          if (a.bias) { const float4 bq = *reinterpret_cast<const float4*>(a.bias + co); v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
+          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+          if (has_r1) { const float4 r = *reinterpret_cast<const float4*>(a.r1 + pix * a.r1_ldc + a.r1_coff + ch);
+                        v.x += a.beta1 * r.x; v.y += a.beta1 * r.y; v.z += a.beta1 * r.z; v.w += a.beta1 * r.w; }
+          if (has_r2) { const float4 r = *reinterpret_cast<const float4*>(a.r2 + pix * a.r2_ldc + a.r2_coff + ch);
+                        v.x += a.beta2 * r.x; v.y += a.beta2 * r.y; v.z += a.beta2 * r.z; v.w += a.beta2 * r.w; }
+          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+          if (has_m) { const float4 q = *reinterpret_cast<const float4*>(a.mask + pix * a.m_ldc + a.m_coff + ch);
+                       v.x *= (q.x > 0.f ? 1.f : a.mask_slope); v.y *= (q.y > 0.f ? 1.f : a.mask_slope);
+                       v.z *= (q.z > 0.f ? 1.f : a.mask_slope); v.w *= (q.w > 0.f ? 1.f : a.mask_slope); }
+#ifdef SRK_NO_STORE
+          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+          *reinterpret_cast<float4*>(a.y + pix * a.y_ldc + a.y_coff + ch) = v;
+#endif
+        }
+      }
+    }
+  } else {
+    // scalar path (Cout not a multiple of 4, e.g. the F->1 tail conv, or unaligned views): one dword per lane
+    const int y_rs = rowmul * a.y_ldc, y_cs = colmul * a.y_ldc;
+    const int r1_rs = rowmul * a.r1_ldc, r1_cs = colmul * a.r1_ldc;
+    const int r2_rs = rowmul * a.r2_ldc, r2_cs = colmul * a.r2_ldc;
+    const int m_rs = rowmul * a.m_ldc, m_cs = colmul * a.m_ldc;
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+      const int co = n0 + t * 32 + l32;
+      if (co >= a.Cout) continue;
+      const float bz = a.bias ? a.bias[co] : 0.f;
+      int ch = co, pi = 0, pj = 0;
+      if (a.ps_out) { const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1; }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ohb = oh0 + 8 * m + 2 * wv, owb = ow0 + 4 * hl;
+        long pix0;
+        if (a.ps_out) pix0 = ((long)(n * 2 * a.OH) + 2 * ohb + pi) * (2 * a.OW) + 2 * owb + pj;
+        else pix0 = ((long)n * a.OH + ohb) * a.OW + owb;
+        float* yb = a.y + pix0 * a.y_ldc + a.y_coff + ch;
+        const float* r1b = has_r1 ? a.r1 + pix0 * a.r1_ldc + a.r1_coff + ch : nullptr;
+        const float* r2b = has_r2 ? a.r2 + pix0 * a.r2_ldc + a.r2_coff + ch : nullptr;
+        const float* mb = has_m ? a.mask + pix0 * a.m_ldc + a.m_coff + ch : nullptr;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rr = reg >> 3, cc = (reg & 3) + 8 * ((reg >> 2) & 1);
+          if (!interior && (ohb + rr >= a.OH || owb + cc >= a.OW)) continue;
+          float v = a.alpha * (acc[m][t][reg] + bz);
+          if (has_r1) v += a.beta1 * r1b[rr * r1_rs + cc * r1_cs];
+          if (has_r2) v += a.beta2 * r2b[rr * r2_rs + cc * r2_cs];
+          v = v > 0.f ? v : v * a.slope;
+          if (has_m) v *= (mb[rr * m_rs + cc * m_cs] > 0.f ? 1.f : a.mask_slope);
+          yb[rr * y_rs + cc * y_cs] = v;
+        }
+      }
     }
   }
+  SRK_STAMP_AT(4);
 }
 
-template <int BN, int S, int MODE, bool VEC>
-int launch(const srk_conv_args& a, hipStream_t st) {
-  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH);
+template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
+int launch_k(const srk_conv_args& a, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * MT);
   const int CoutP = srk_round_up(a.Cout, 32);
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)srk_div_up(CoutP, BN));
-  hipLaunchKernelGGL((conv3x3_f32_kernel<BN, S, MODE, VEC>), grid, dim3(SRK_THREADS), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_f32_kernel<BN, S, MODE, VEC, MT, DMA>), grid, dim3(SRK_THREADS), 0, st, a);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
 
+// The global->LDS DMA variant (DMA = true) is correct but measured SLOWER than register staging on gfx950
+// (80 vs 73.6 cycles per MFMA at one workgroup per CU: each buffer_load...lds piece costs the issuing MFMA wave
+// more issue time than a buffer_load + ds_write_b128 pair), so it is not dispatched.
+template <int BN, int S, int MODE, bool VEC, int MT>
+int launch(const srk_conv_args& a, hipStream_t st) {
+  return launch_k<BN, S, MODE, VEC, MT, false>(a, st);
+}
+
+// Tile choice: 16x16 pixels (two M tiles per wave: twice the MFMA work per LDS fragment and per barrier)
+// whenever the image is tall enough that the 16-row tile wastes no more rows than the 8-row one.
 template <int S, int MODE, bool VEC>
 int launch_bn(const srk_conv_args& a, hipStream_t st) {
   if constexpr (S == 1) {
-    if (a.Cout > 32) return launch<64, S, MODE, VEC>(a, st);
+    const bool tall = srk_round_up(a.OH, 16) == srk_round_up(a.OH, 8);
+    if (a.Cout > 32) return tall ? launch<64, S, MODE, VEC, 2>(a, st) : launch<64, S, MODE, VEC, 1>(a, st);
+    return tall ? launch<32, S, MODE, VEC, 2>(a, st) : launch<32, S, MODE, VEC, 1>(a, st);
   }
-  return launch<32, S, MODE, VEC>(a, st);
+  return launch<32, S, MODE, VEC, 1>(a, st);
 }
 
 }  // namespace
