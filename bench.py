@@ -138,8 +138,9 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(name)
+                try:   # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                    # same command (tools/traffic_from_pmc.py; FETCH_SIZE x2 on gfx950), not collectable in-process
+                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
