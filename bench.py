@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -52,28 +53,45 @@ def synth_batch(n, device, seed):
     return lr.contiguous(), hr.contiguous()
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box exposes
+    256 logical CPUs but a 16-CPU quota; oversubscribing it makes the baseline ~10x slower than it is)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(res_blocks, workload):
     """Times the CPU oracle (a port of the reference's step, oracle/esrgan_oracle.py) on this box's host cores
-    on a bounded sample; baseline only."""
+    on a bounded sample (batch 4, 1 warm-up + up to 4 timed iterations, ~10-30 s); baseline only."""
     from oracle import esrgan_oracle as O
-    n = 2
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = 4
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
     params = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999))
     lr, hr = O.jet_images(n, 1, HR, HR, 1234, FACTOR)
     times = []
-    for it in range(3):
+    for it in range(5):
         t0 = time.perf_counter()
         opt.zero_grad()
         y, _ = O.generator_forward(params, lr, res_blocks, 2, 0.2, training=True)
         O.warmup_loss(y, hr).backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / len(times[1:])
+        print(f"[cpu_baseline] iter {it}: {times[-1]:.1f} s on {cores} threads", file=sys.stderr, flush=True)
+        if it >= 1 and sum(times) > 25.0:
+            break
+    timed = times[1:]
+    dt = sum(timed) / len(timed)
     return {"value": n * HR * HR / dt, "unit": "HR-px/s", "cores": cores, "kind": "port",
-            "sample": f"G-only step (fwd+L1+bwd+Adam) of the same generator, batch {n}, 1 warm-up + 2 timed iters, "
+            "sample": f"G-only step (fwd+L1+bwd+Adam) of the same generator, batch {n}, 1 warm-up + {len(timed)} timed iters, "
                       f"{dt*1e3:.0f} ms/iter, torch CPU fp32"}
 
 

@@ -1,0 +1,246 @@
+"""Train entrypoint of the MI355X build: ``get_parser()`` / ``train(opt, **kwargs)``.
+
+Mirrors the *interface* of the reference's esrgan.py (flags and their defaults: esrgan.py:30-149 +
+options/default.json; step semantics: esrgan.py:399-626; checkpoint and info.json names: esrgan.py:163,370-391;
+NaN guard: esrgan.py:645-648) for the hot-path options, so existing launch scripts and hyper-search drivers keep
+working.  The iteration itself is ``train.Stepper`` (HIP kernels, optional data parallelism); the physics loss heads
+that default to 0 in the reference (hist / wasser / nnz / mask / hit), the conditional / Wasserstein discriminators,
+validation/evaluation plots and the HDF5 jet datasets are outside this build's scope -- asking for
+them raises instead of silently training something else.
+
+Multi-GPU: launch one process per GPU, e.g.
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m super-resolution_amd.esrgan ...
+(the hyphenated package name needs ``python -c "import runpy; runpy.run_module('super-resolution_amd.esrgan', run_name='__main__')"``
+or tools/train.py); each rank trains on its shard of every batch and gradients are averaged over RCCL.
+"""
+import argparse
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import train as _train
+
+# values of the reference's options/default.json for the options this build implements
+DEFAULTS = dict(
+    n_epochs=50, dataset_path="../data/tops_80.h5", dataset_type="synthetic", batch_size=8, factor=2, lr=0.0002, lr_g=0.0,
+    lr_d=0.0, l2decay=0.0, b1=0.9, b2=0.999, hr_height=80, hr_width=80, channels=1, scaling_power=1, residual_blocks=10,
+    warmup_batches=500, pixel_multiplier=1, lambda_pix=0.2, lambda_hr=1, lambda_adv=0.01, lambda_lr=0.1, lambda_hist=0,
+    lambda_wasser=0, lambda_nnz=0, lambda_mask=0, lambda_pow=1, lambda_hit=0, learn_warmup=True, name="", root="",
+    model_path="saved_models", load_checkpoint=None, report_freq=10, discriminator="patch", relativistic=True, save=True,
+    save_info=None, checkpoint_interval=500, n_checkpoints=-1, n_batches=-1, d_threshold=0.001, d_channels=[16, 32, 32, 64],
+    E_thres=None, set_seed=-1, drop_rate=0, res_scale=0.1, lambda_reg=0.01, update_d=1, update_g=1, conditional=False,
+    wasserstein=-1, second_discr_reset_interval=0, uniform_init=False, use_transposed_conv=False,
+    fully_transposed_conv=False, num_final_res_blocks=0, synthetic_batches=100,
+)
+UNSUPPORTED_POSITIVE = ("lambda_hist", "lambda_wasser", "lambda_nnz", "lambda_mask", "lambda_hit", "drop_rate",
+                        "second_discr_reset_interval")
+LOSS_KEYS = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
+             'pixel_loss_pow', 'lr_loss', 'lr_loss_pow']
+
+
+def _str2bool(v):
+    return v if isinstance(v, bool) else str(v).lower() in ("1", "true", "yes", "y")
+
+
+def get_parser(argv=None):
+    """argparse Namespace with the reference's flag names (esrgan.py:30-149); ``--default file.json`` overlays a json of
+    options, explicit command-line flags win (esrgan.py:135-147)."""
+    ap = argparse.ArgumentParser(description="ESRGAN training on MI355X (super-resolution_amd)")
+    for k, v in DEFAULTS.items():
+        if isinstance(v, bool):
+            ap.add_argument("--" + k, type=_str2bool, default=v)
+        elif isinstance(v, list):
+            ap.add_argument("--" + k, type=int, nargs="+", default=v)
+        elif v is None:
+            ap.add_argument("--" + k, default=None, type=(float if k == "E_thres" else str))
+        else:
+            ap.add_argument("--" + k, type=type(v), default=v)
+    ap.add_argument("--default", type=str, default=None, help="json file with option overrides")
+    opt = ap.parse_args(argv)
+    if opt.default:
+        with open(opt.default) as f:
+            over = json.load(f)
+        for k, v in over.items():
+            if k in DEFAULTS and getattr(opt, k) == DEFAULTS[k]:      # non-default CLI values win
+                setattr(opt, k, v)
+    return opt
+
+
+def options(**kw):
+    """Programmatic equivalent of get_parser(): defaults + overrides (hyper-search style callers)."""
+    d = dict(DEFAULTS)
+    unknown = set(kw) - set(d)
+    if unknown:
+        raise TypeError(f"unknown option(s): {sorted(unknown)}")
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+class SyntheticJets(torch.utils.data.Dataset):
+    """Sparse non-negative jet-like images; LR = SumPool(HR) as datasets.py:227,247 builds it."""
+
+    def __init__(self, n, channels, hr_h, hr_w, factor, seed=1234):
+        g = torch.Generator().manual_seed(seed)
+        self.hr = 10.0 * torch.rand(n, channels, hr_h, hr_w, generator=g) * (torch.rand(n, channels, hr_h, hr_w, generator=g) < 0.1).float()
+        self.lr = (factor * factor) * torch.nn.functional.avg_pool2d(self.hr, factor)
+
+    def __len__(self):
+        return self.hr.shape[0]
+
+    def __getitem__(self, i):
+        return {"lr": self.lr[i], "hr": self.hr[i]}
+
+
+def _check_supported(opt):
+    for k in UNSUPPORTED_POSITIVE:
+        if getattr(opt, k, 0) and getattr(opt, k) > 0:
+            raise NotImplementedError(f"option {k} > 0 is outside the hot path implemented by this build (SURVEY.md 2.1)")
+    if opt.discriminator != "patch" or opt.conditional or opt.wasserstein > 0:
+        raise NotImplementedError("only the default patch (Markovian) discriminator with the relativistic loss is implemented")
+    if not opt.relativistic:
+        raise NotImplementedError("non-relativistic adversarial loss is not implemented")
+    if opt.use_transposed_conv or opt.fully_transposed_conv:
+        raise NotImplementedError("transposed-conv upsampling branches are not implemented")
+
+
+def train(opt, **kwargs):
+    """Runs the training loop; returns the ``info`` dict that is also written to ``<model_path>/<name_>info.json``.
+    kwargs: ``gpu`` (device index, esrgan.py:156), ``dataset`` (a torch Dataset yielding {"lr","hr"}; default synthetic)."""
+    _check_supported(opt)
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", kwargs.get("gpu", 0)))
+    if not torch.cuda.is_available():
+        raise RuntimeError("super-resolution_amd.esrgan.train needs a ROCm GPU (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=device)
+    model_name = "" if not opt.name else opt.name + "_"
+    out_dir = os.path.join(opt.root, opt.model_path)
+    info_path = os.path.join(out_dir, model_name + "info.json")
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+    info = {"epochs": 0, "argument": dict(vars(opt))}
+    if opt.set_seed > 0:
+        torch.manual_seed(opt.set_seed)
+        np.random.seed(opt.set_seed)
+        info["seed"] = opt.set_seed
+    else:
+        torch.manual_seed(0)            # replicas must start identical on every rank
+
+    st = _train.Stepper(workload="gan", res_blocks=opt.residual_blocks, device=device, factor=opt.factor,
+                        distributed=(world > 1), channels=opt.channels, res_scale=opt.res_scale,
+                        lr=opt.lr, lr_g=opt.lr_g, lr_d=opt.lr_d, betas=(opt.b1, opt.b2), weight_decay=opt.l2decay,
+                        d_channels=tuple(opt.d_channels), lambdas=(opt.lambda_pix, opt.lambda_pow), lambda_hr=opt.lambda_hr,
+                        lambda_adv=opt.lambda_adv, lambda_lr=opt.lambda_lr, lambda_reg=opt.lambda_reg, d_threshold=opt.d_threshold,
+                        scaling_power=opt.scaling_power, multiplier=opt.pixel_multiplier, hr_shape=(opt.hr_height, opt.hr_width),
+                        num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init)
+    if opt.E_thres:
+        st.generator.thres = opt.E_thres
+    load_chk = bool(opt.load_checkpoint)
+    if load_chk:
+        st.generator.load_state_dict(torch.load(opt.load_checkpoint, map_location=device))
+        gfile = os.path.basename(opt.load_checkpoint)
+        for k, D in st.discriminators.items():
+            dpath = opt.load_checkpoint.replace(gfile, gfile.replace("generator", ["discriminator", "discriminator_pow"][k]))
+            if os.path.exists(dpath):
+                D.load_state_dict(torch.load(dpath, map_location=device))
+        if model_name == "":
+            model_name = gfile.split("generator")[0]
+            info_path = os.path.join(out_dir, model_name + "info.json")
+        if os.path.exists(info_path):
+            with open(info_path) as f:
+                info = json.load(f)
+
+    dataset = kwargs.get("dataset")
+    if dataset is None:
+        if opt.dataset_type != "synthetic":
+            raise NotImplementedError("the HDF5 jet datasets (datasets.py) are outside this build; pass dataset=... or use "
+                                      "--dataset_type synthetic")
+        dataset = SyntheticJets(opt.synthetic_batches * opt.batch_size, opt.channels, opt.hr_height, opt.hr_width, opt.factor)
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+    per_rank = max(opt.batch_size // world, 1)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler, drop_last=(world > 1))
+
+    loss_dict = info.get("loss") or {k: [] for k in LOSS_KEYS}
+    batches_trained = int(info.get("batches_done", 0))
+    start_epoch = int(info.get("epochs", 0))
+    n_batches = math.inf if opt.n_batches == -1 else opt.n_batches
+    total_batches = len(loader) * (opt.n_epochs - start_epoch) if n_batches == math.inf else n_batches + batches_trained
+    batches_done = batches_trained - 1
+    save_info_file = opt.save_info if opt.save_info is not None else opt.save
+
+    def save_info():
+        if save_info_file and rank == 0:
+            info["loss"] = loss_dict
+            info["batches_done"] = batches_done
+            with open(info_path, "w") as f:
+                json.dump(info, f)
+
+    def save_weights(epoch):
+        if not opt.save or rank != 0:
+            return
+        suffix = "_continued" if load_chk else ""
+        torch.save(st.generator.state_dict(), os.path.join(out_dir, "%sgenerator_%d%s.pth" % (model_name, epoch, suffix)))
+        for k, D in st.discriminators.items():
+            torch.save(D.state_dict(), os.path.join(out_dir, "%sdiscriminator%s_%d%s.pth" % (model_name, ["", "_pow"][k], epoch, suffix)))
+        save_info()
+
+    for epoch in range(start_epoch, opt.n_epochs + start_epoch):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        for i, imgs in enumerate(loader):
+            batches_done += 1
+            imgs_lr = imgs["lr"].to(device).float()
+            imgs_hr = imgs["hr"].to(device).float()
+            warm = (not load_chk) and (batches_done - batches_trained < opt.warmup_batches)
+            if warm:
+                if opt.learn_warmup:
+                    out = st.warmup_step(imgs_lr, imgs_hr)
+                    if batches_done % opt.report_freq == 0:
+                        v = out["g_loss"].item()
+                        loss_dict["g_loss"].append(v); loss_dict["pixel_loss"].append(v)
+                        if rank == 0:
+                            print("[Batch %d/%d] [Epoch %d/%d] [G pixel: %f]" % (i, total_batches, epoch, opt.n_epochs, v))
+                continue
+            do_g = (i == opt.warmup_batches) or (batches_done % opt.update_g == 0)
+            do_d = (i == opt.warmup_batches) or (batches_done % opt.update_d == 0)
+            out = st.gan_step(imgs_lr, imgs_hr, update_g=do_g, update_d=do_d)
+            vals = st.loss_scalars(out)                      # one host sync for the whole report
+            if any(v != v for v in (vals["d_loss_def"], vals["d_loss_pow"], vals["g_loss"])):
+                save_info()
+                raise ValueError("loss is NaN\n[Batch %d] [D def: %e, pow: %e] [G loss: %f]" %
+                                 (i, vals["d_loss_def"], vals["d_loss_pow"], vals["g_loss"]))
+            if batches_done % opt.report_freq == 0:
+                for k in LOSS_KEYS:
+                    loss_dict[k].append(vals[k])
+                if rank == 0:
+                    print("[Batch %d] [D def: %f, pow: %f] [G loss: %f [def: %f, pow: %f], adv: %f, adv pow: %f, pixel: %f, "
+                          "pixel pow: %f, lr pixel: %f, lr pixel pow: %f]" % ((batches_done,) + tuple(vals[k] for k in LOSS_KEYS)))
+            if opt.n_checkpoints == -1 and opt.checkpoint_interval > 0 and batches_done % opt.checkpoint_interval == 0 and batches_done > 0:
+                save_weights(epoch)
+            if batches_done + 1 >= total_batches:
+                break
+        info["epochs"] = epoch + 1
+        if batches_done + 1 >= total_batches:
+            break
+    save_weights(info["epochs"])
+    save_info()
+    info["loss"] = loss_dict
+    info["batches_done"] = batches_done
+    return info
+
+
+if __name__ == "__main__":
+    print(json.dumps({k: v for k, v in train(get_parser()).items() if k != "loss"}, default=str))

@@ -44,7 +44,8 @@ class Stepper:
     def __init__(self, workload="g_only", res_blocks=23, device=None, hr=256, factor=4, distributed=False, channels=1,
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
-                 exact_dp=True, hr_shape=None):
+                 exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
+                 uniform_init=False):
         self.workload = workload
         self.device = device
         self.distributed = distributed
@@ -57,8 +58,11 @@ class Stepper:
         hr_shape = hr_shape or (hr, hr)
         self.generator = models.GeneratorRRDB(channels, filters=filters, num_res_blocks=res_blocks,
                                               num_upsample=int(math.log2(factor)), res_scale=res_scale,
-                                              power=scaling_power).to(device)
-        self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=betas, fused=True)
+                                              power=scaling_power, multiplier=multiplier, num_final_layer_res=num_final_layer_res,
+                                              uniform_init=uniform_init).to(device)
+        # esrgan.py:299,305: Adam(lr_g or lr), Adam(lr_d or lr); fused=True is the same arithmetic in one launch
+        self.optimizer_G = torch.optim.Adam([p for p in self.generator.parameters() if p.requires_grad],
+                                            lr=lr_g if lr_g > 0 else lr, betas=betas, weight_decay=weight_decay, fused=True)
         self.criterion_pixel = nn.L1Loss()
         self.criterion_GAN = nn.BCEWithLogitsLoss()
         self.pool = models.SumPool2d(factor)
@@ -68,7 +72,7 @@ class Stepper:
                 if self.lambdas[k] > 0:
                     D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     self.discriminators[k] = D
-                    self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr, betas=betas, fused=True)
+                    self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas, fused=True)
         if distributed:
             self.generator._engine.enable_grad_sync()
         self.last = {}
@@ -93,11 +97,26 @@ class Stepper:
 
     def step(self, imgs_lr, imgs_hr):
         if self.workload == "g_only":
-            return self._warmup_step(imgs_lr, imgs_hr)
-        return self._gan_step(imgs_lr, imgs_hr)
+            return self.warmup_step(imgs_lr, imgs_hr)
+        return self.gan_step(imgs_lr, imgs_hr)
+
+    def loss_scalars(self, out):
+        """Python floats of one iteration's losses under the reference's loss_dict names (esrgan.py:355), fetched
+        with ONE device->host copy instead of ~20 ``.item()`` calls (esrgan.py:632-645)."""
+        z = torch.zeros((), device=self.device)
+        parts = out.get("parts", {})
+        d = out.get("d_loss", {})
+
+        def g(k, name):
+            return parts[k][name].reshape(()) if k in parts else z
+        vec = torch.stack([d.get(0, z).reshape(()), d.get(1, z).reshape(()), out["g_loss"].reshape(()), g(0, "tot"), g(1, "tot"),
+                           g(0, "adv"), g(1, "adv"), g(0, "pixel"), g(1, "pixel"), g(0, "lr"), g(1, "lr")]).tolist()
+        names = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
+                 'pixel_loss_pow', 'lr_loss', 'lr_loss_pow']
+        return dict(zip(names, vec))
 
     # ------------------------------------------------------------------ warm-up iteration
-    def _warmup_step(self, imgs_lr, imgs_hr):
+    def warmup_step(self, imgs_lr, imgs_hr):
         """esrgan.py:416-427."""
         self.optimizer_G.zero_grad(set_to_none=True)
         gen_hr = self.generator(imgs_lr)
@@ -167,15 +186,21 @@ class Stepper:
             loss_D = loss_D + gp
         return loss_D, gp
 
-    def _gan_step(self, imgs_lr, imgs_hr, epsilons=None):
+    def gan_step(self, imgs_lr, imgs_hr, epsilons=None, update_g=True, update_d=True):
         # ---- generator (esrgan.py:416,457-555)
         self.optimizer_G.zero_grad(set_to_none=True)
-        loss_G, generated, ground_truth, parts = self.g_phase_loss(imgs_lr, imgs_hr)
-        loss_G.backward()
-        self.optimizer_G.step()
+        if update_g:
+            loss_G, generated, ground_truth, parts = self.g_phase_loss(imgs_lr, imgs_hr)
+            loss_G.backward()
+            self.optimizer_G.step()
+        else:       # the D phase still needs the generator output (esrgan.py:457 skips only the G update)
+            with torch.no_grad():
+                generated = [self.generator(imgs_lr), self.generator.srs]
+            ground_truth = [imgs_hr, imgs_hr ** self.scaling_power]
+            loss_G, parts = torch.zeros(1, device=imgs_lr.device), {}
         # ---- discriminators (esrgan.py:561-626); they see the pre-update generator output
         loss_D_tot = {}
-        for k, D in self.discriminators.items():
+        for k, D in (self.discriminators.items() if update_d else ()):
             self.optimizer_D[k].zero_grad(set_to_none=True)
             loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k])
             loss_D.backward()
