@@ -155,6 +155,8 @@ def _conv_kernel_name(a) -> str:
     vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
     bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
     mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
+    if a.stride == 1 and vec and mt == 2 and bn == 64 and a.in_mode != IN_ZERO_UPSAMPLE and os.environ.get("SRK_CONV_LW", "1") != "0":
+        return f"conv3x3_f32_lw_kernel<{bn}, {a.in_mode}>"
     dma = False   # the DMA staging variant is compiled out of the dispatch (slower on gfx950, see srk_conv.hip)
     return f"conv3x3_f32_kernel<{bn}, {a.stride}, {a.in_mode}, {'true' if vec else 'false'}, {mt}, {'true' if dma else 'false'}>"
 

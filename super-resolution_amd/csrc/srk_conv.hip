@@ -15,6 +15,7 @@
 // Mirrors: nn.Conv2d/LeakyReLU/cat/mul+add/PixelShuffle of /root/reference/models.py:19-21,36-41,53,
 // 63,67,86-90,97-99,126,142-145,168 (forward) and their autograd data-gradients.
 #include "srk_internal.h"
+#include <stdlib.h>
 
 #ifdef SRK_STAMP
 // diagnostic build only: per-workgroup phase stamps (s_memrealtime, 100 MHz) into a side buffer
@@ -46,6 +47,117 @@ struct Geo {
   static constexpr int NX4 = 2 * NHP;               // float4 per chunk (8 ch per pixel)
   static constexpr int NXS = (NX4 + SRK_THREADS - 1) / SRK_THREADS;  // slots per thread
 };
+
+// Fused epilogue shared by the conv kernels.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of M tile m
+// (rows 2wv, 2wv+1 of the m-th 8-row group), channel = n0 + 32t + l32.
+template <int BN, int MT>
+__device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float4* smem, int n, int oh0,
+                                              int ow0, int n0, int wv, int lane) {
+  constexpr int NTN = BN / 32;
+  const int hl = lane >> 5, l32 = lane & 31;
+  // ---- epilogue.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of the M tile, channel = n0 + 32t + l32.
+  // Inside one M tile the lane's 16 registers are 2 rows x 8 columns {c, c+1, c+2, c+3, c+8, .., c+11} with
+  // c = 4*hl: every address is  base + (reg>>3)*row_stride + col(reg)*col_stride  (32-bit offsets from one
+  // 64-bit base per tensor), and interior tiles skip all bounds checks.
+  const int Cps_out = a.Cout >> 2;
+  const bool interior = (oh0 + (SRK_TH * MT) <= a.OH) && (ow0 + SRK_TW <= a.OW);
+  const int rowmul = a.ps_out ? 4 * a.OW : a.OW, colmul = a.ps_out ? 2 : 1;   // physical pixel steps per logical row/col
+  constexpr int NG = NTN * MT;
+  const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.mask != nullptr;
+  // 16-byte path: every tensor the epilogue touches is float4-addressable per pixel
+  const bool vec_out = ((a.Cout & 3) == 0) && (!a.ps_out || (Cps_out & 3) == 0) &&
+                       ((a.y_ldc | a.y_coff) & 3) == 0 && (((uintptr_t)a.y) & 15) == 0 &&
+                       (!a.bias || (((uintptr_t)a.bias) & 15) == 0) &&
+                       (!has_r1 || ((((a.r1_ldc | a.r1_coff) & 3) == 0) && (((uintptr_t)a.r1) & 15) == 0)) &&
+                       (!has_r2 || ((((a.r2_ldc | a.r2_coff) & 3) == 0) && (((uintptr_t)a.r2) & 15) == 0)) &&
+                       (!has_m || ((((a.m_ldc | a.m_coff) & 3) == 0) && (((uintptr_t)a.mask) & 15) == 0));
+  if (vec_out) {
+    // Transpose each 32 px x 32 ch accumulator tile through this wave's private 4 KB of LDS so that a lane
+    // owns 4 consecutive channels of one pixel: 16-byte loads/stores, 4x fewer store instructions (the
+    // store tail is issue-bound).  The main loop's last barrier has retired every other use of the LDS.
+    float* ls = reinterpret_cast<float*>(smem) + wv * 1024;
+    float4* ls4 = reinterpret_cast<float4*>(ls);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int t = g / MT, m = g % MT;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+        ls[i * 32 + l32] = acc[m][t][reg];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = j * 64 + lane;
+        const int pl = idx >> 3, c4 = idx & 7;
+        const int oh = oh0 + 8 * m + 2 * wv + (pl >> 4), ow = ow0 + (pl & 15);
+        const int co = n0 + t * 32 + 4 * c4;
+        float4 v = ls4[idx];
+        if (co < a.Cout && (interior || (oh < a.OH && ow < a.OW))) {
+          int ch = co, pi = 0, pj = 0;
+          long pix;
+          if (a.ps_out) {
+            const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1;
+            pix = ((long)(n * 2 * a.OH) + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj;
+          } else {
+            pix = ((long)n * a.OH + oh) * a.OW + ow;
+          }
+          if (a.bias) { const float4 bq = *reinterpret_cast<const float4*>(a.bias + co); v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
+          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+          if (has_r1) { const float4 r = *reinterpret_cast<const float4*>(a.r1 + pix * a.r1_ldc + a.r1_coff + ch);
+                        v.x += a.beta1 * r.x; v.y += a.beta1 * r.y; v.z += a.beta1 * r.z; v.w += a.beta1 * r.w; }
+          if (has_r2) { const float4 r = *reinterpret_cast<const float4*>(a.r2 + pix * a.r2_ldc + a.r2_coff + ch);
+                        v.x += a.beta2 * r.x; v.y += a.beta2 * r.y; v.z += a.beta2 * r.z; v.w += a.beta2 * r.w; }
+          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+          if (has_m) { const float4 q = *reinterpret_cast<const float4*>(a.mask + pix * a.m_ldc + a.m_coff + ch);
+                       v.x *= (q.x > 0.f ? 1.f : a.mask_slope); v.y *= (q.y > 0.f ? 1.f : a.mask_slope);
+                       v.z *= (q.z > 0.f ? 1.f : a.mask_slope); v.w *= (q.w > 0.f ? 1.f : a.mask_slope); }
+#ifdef SRK_NO_STORE
+          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+          *reinterpret_cast<float4*>(a.y + pix * a.y_ldc + a.y_coff + ch) = v;
+#endif
+        }
+      }
+    }
+  } else {
+    // scalar path (Cout not a multiple of 4, e.g. the F->1 tail conv, or unaligned views): one dword per lane
+    const int y_rs = rowmul * a.y_ldc, y_cs = colmul * a.y_ldc;
+    const int r1_rs = rowmul * a.r1_ldc, r1_cs = colmul * a.r1_ldc;
+    const int r2_rs = rowmul * a.r2_ldc, r2_cs = colmul * a.r2_ldc;
+    const int m_rs = rowmul * a.m_ldc, m_cs = colmul * a.m_ldc;
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+      const int co = n0 + t * 32 + l32;
+      if (co >= a.Cout) continue;
+      const float bz = a.bias ? a.bias[co] : 0.f;
+      int ch = co, pi = 0, pj = 0;
+      if (a.ps_out) { const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1; }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ohb = oh0 + 8 * m + 2 * wv, owb = ow0 + 4 * hl;
+        long pix0;
+        if (a.ps_out) pix0 = ((long)(n * 2 * a.OH) + 2 * ohb + pi) * (2 * a.OW) + 2 * owb + pj;
+        else pix0 = ((long)n * a.OH + ohb) * a.OW + owb;
+        float* yb = a.y + pix0 * a.y_ldc + a.y_coff + ch;
+        const float* r1b = has_r1 ? a.r1 + pix0 * a.r1_ldc + a.r1_coff + ch : nullptr;
+        const float* r2b = has_r2 ? a.r2 + pix0 * a.r2_ldc + a.r2_coff + ch : nullptr;
+        const float* mb = has_m ? a.mask + pix0 * a.m_ldc + a.m_coff + ch : nullptr;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rr = reg >> 3, cc = (reg & 3) + 8 * ((reg >> 2) & 1);
+          if (!interior && (ohb + rr >= a.OH || owb + cc >= a.OW)) continue;
+          float v = a.alpha * (acc[m][t][reg] + bz);
+          if (has_r1) v += a.beta1 * r1b[rr * r1_rs + cc * r1_cs];
+          if (has_r2) v += a.beta2 * r2b[rr * r2_rs + cc * r2_cs];
+          v = v > 0.f ? v : v * a.slope;
+          if (has_m) v *= (mb[rr * m_rs + cc * m_cs] > 0.f ? 1.f : a.mask_slope);
+          yb[rr * y_rs + cc * y_cs] = v;
+        }
+      }
+    }
+  }
+}
 
 // one 16-byte-per-lane global -> LDS DMA piece (buffer_load_dwordx4 ... lds); lds_dst is wave-uniform
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float4* lds_dst, unsigned voffset, unsigned soffset) {
@@ -304,109 +416,174 @@ __global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv
   SRK_SEG_END();
   SRK_CLOCK_AT(6);
   SRK_STAMP_AT(3);
-  // ---- epilogue.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of the M tile, channel = n0 + 32t + l32.
-  // Inside one M tile the lane's 16 registers are 2 rows x 8 columns {c, c+1, c+2, c+3, c+8, .., c+11} with
-  // c = 4*hl: every address is  base + (reg>>3)*row_stride + col(reg)*col_stride  (32-bit offsets from one
-  // 64-bit base per tensor), and interior tiles skip all bounds checks.
-  const int Cps_out = a.Cout >> 2;
-  const bool interior = (oh0 + G::TH <= a.OH) && (ow0 + SRK_TW <= a.OW);
-  const int rowmul = a.ps_out ? 4 * a.OW : a.OW, colmul = a.ps_out ? 2 : 1;   // physical pixel steps per logical row/col
-  constexpr int NG = NTN * MT;
-  const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.mask != nullptr;
-  // 16-byte path: every tensor the epilogue touches is float4-addressable per pixel
-  const bool vec_out = ((a.Cout & 3) == 0) && (!a.ps_out || (Cps_out & 3) == 0) &&
-                       ((a.y_ldc | a.y_coff) & 3) == 0 && (((uintptr_t)a.y) & 15) == 0 &&
-                       (!a.bias || (((uintptr_t)a.bias) & 15) == 0) &&
-                       (!has_r1 || ((((a.r1_ldc | a.r1_coff) & 3) == 0) && (((uintptr_t)a.r1) & 15) == 0)) &&
-                       (!has_r2 || ((((a.r2_ldc | a.r2_coff) & 3) == 0) && (((uintptr_t)a.r2) & 15) == 0)) &&
-                       (!has_m || ((((a.m_ldc | a.m_coff) & 3) == 0) && (((uintptr_t)a.mask) & 15) == 0));
-  if (vec_out) {
-    // Transpose each 32 px x 32 ch accumulator tile through this wave's private 4 KB of LDS so that a lane
-    // owns 4 consecutive channels of one pixel: 16-byte loads/stores, 4x fewer store instructions (the
-    // store tail is issue-bound).  The main loop's last barrier has retired every other use of the LDS.
-    float* ls = reinterpret_cast<float*>(smem) + wv * 1024;
-    float4* ls4 = reinterpret_cast<float4*>(ls);
+  conv_epilogue<BN, MT>(a, acc, smem, n, oh0, ow0, n0, wv, lane);
+  SRK_STAMP_AT(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Loader-wave variant (stride 1, 16x16 tile, 16-byte-addressable input): 5 waves per workgroup.  Waves 0-3 run
+// ONLY the MFMA stream (fragment reads + MFMAs + epilogue); wave 4 does all global->LDS staging of the next
+// K-chunk.  Measured motivation (tools/stamp_conv.py): each buffer_load / ds_write_b128 costs the wave that issues
+// it ~65 cycles of its in-order issue stream, 16 of them per chunk put the MFMA waves at 73.6 cycles/MFMA instead
+// of the pipe's 64; moved to a fifth wave that cost overlaps the matrix pipe instead of stalling it.
+template <int BN, int MODE>
+__global__ __launch_bounds__(320) void conv3x3_f32_lw_kernel(const srk_conv_args a) {
+  constexpr int S = 1, MT = 2;
+  using G = Geo<S, MT>;
+  constexpr int NW4 = 18 * BN;
+  constexpr int NTN = BN / 32;
+  constexpr int BUF4 = G::NX4 + NW4;
+  constexpr int NXL = (G::NX4 + 63) / 64;          // loader slots (one float4 per lane each): input halo
+  constexpr int NWL = (NW4 + 63) / 64;             //                                          weights
+  constexpr int NL = NXL + NWL;
+  constexpr int LB = 8;                            // loader batch: loads in flight before their ds_writes
+  __shared__ float4 smem[2 * BUF4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + G::TH - 1) / G::TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * G::TH, ow0 = tx * SRK_TW, n0 = blockIdx.y * BN;
+  const int CoutP = (a.Cout + 31) & ~31;
+  const int nq = (a.Cin + 7) >> 3;
+
+  if (wv == 4) {
+    // ------------------------------------------------------------------ loader wave
+    const int Cps_in = a.Cin >> 2;
+    constexpr unsigned OOB = 0x80000000u;
+    long img_elems = (long)a.H * a.W * a.x_ldc;
+    if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+    const float* ximg = a.x + (long)n * img_elems;
+    const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
+    const unsigned wbytes = (unsigned)((long)nq * 18 * CoutP * 16);
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+    unsigned vo[NL];
+    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int t = g / MT, m = g % MT;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
-        ls[i * 32 + l32] = acc[m][t][reg];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = j * 64 + lane;
-        const int pl = idx >> 3, c4 = idx & 7;
-        const int oh = oh0 + 8 * m + 2 * wv + (pl >> 4), ow = ow0 + (pl & 15);
-        const int co = n0 + t * 32 + 4 * c4;
-        float4 v = ls4[idx];
-        if (co < a.Cout && (interior || (oh < a.OH && ow < a.OW))) {
-          int ch = co, pi = 0, pj = 0;
-          long pix;
-          if (a.ps_out) {
-            const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1;
-            pix = ((long)(n * 2 * a.OH) + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj;
-          } else {
-            pix = ((long)n * a.OH + oh) * a.OW + ow;
-          }
-          if (a.bias) { const float4 bq = *reinterpret_cast<const float4*>(a.bias + co); v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
-          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
-          if (has_r1) { const float4 r = *reinterpret_cast<const float4*>(a.r1 + pix * a.r1_ldc + a.r1_coff + ch);
-                        v.x += a.beta1 * r.x; v.y += a.beta1 * r.y; v.z += a.beta1 * r.z; v.w += a.beta1 * r.w; }
-          if (has_r2) { const float4 r = *reinterpret_cast<const float4*>(a.r2 + pix * a.r2_ldc + a.r2_coff + ch);
-                        v.x += a.beta2 * r.x; v.y += a.beta2 * r.y; v.z += a.beta2 * r.z; v.w += a.beta2 * r.w; }
-          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-          if (has_m) { const float4 q = *reinterpret_cast<const float4*>(a.mask + pix * a.m_ldc + a.m_coff + ch);
-                       v.x *= (q.x > 0.f ? 1.f : a.mask_slope); v.y *= (q.y > 0.f ? 1.f : a.mask_slope);
-                       v.z *= (q.z > 0.f ? 1.f : a.mask_slope); v.w *= (q.w > 0.f ? 1.f : a.mask_slope); }
-#ifdef SRK_NO_STORE
-          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#else
-          *reinterpret_cast<float4*>(a.y + pix * a.y_ldc + a.y_coff + ch) = v;
-#endif
-        }
-      }
+    for (int i = 0; i < NXL; ++i) {
+      const int idx = lane + i * 64;
+      const int hp = idx >> 1, half = idx & 1;
+      const int hy = hp / G::IW, hx = hp - hy * G::IW;
+      const int ih = ih0 + hy, iw = iw0 + hx;
+      const bool inb = idx < G::NX4 && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+      long off;
+      if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 4 * half;
+      else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 4 * half;
+      vo[i] = inb ? (unsigned)(off * 4) : OOB;
     }
-  } else {
-    // scalar path (Cout not a multiple of 4, e.g. the F->1 tail conv, or unaligned views): one dword per lane
-    const int y_rs = rowmul * a.y_ldc, y_cs = colmul * a.y_ldc;
-    const int r1_rs = rowmul * a.r1_ldc, r1_cs = colmul * a.r1_ldc;
-    const int r2_rs = rowmul * a.r2_ldc, r2_cs = colmul * a.r2_ldc;
-    const int m_rs = rowmul * a.m_ldc, m_cs = colmul * a.m_ldc;
 #pragma unroll
-    for (int t = 0; t < NTN; ++t) {
-      const int co = n0 + t * 32 + l32;
-      if (co >= a.Cout) continue;
-      const float bz = a.bias ? a.bias[co] : 0.f;
-      int ch = co, pi = 0, pj = 0;
-      if (a.ps_out) { const int ij = co / Cps_out; ch = co - ij * Cps_out; pi = ij >> 1; pj = ij & 1; }
+    for (int i = 0; i < NWL; ++i) {
+      const int idx = lane + i * 64;
+      const int th = idx / BN, co = idx - th * BN;
+      vo[NXL + i] = (idx < NW4 && n0 + co < CoutP) ? (unsigned)((th * CoutP + n0 + co) * 16) : OOB;
+    }
+    const float in_slope = a.in_slope;
+    auto stage = [&](int q, int b) {
+      unsigned xso = (unsigned)(8 * q * 4);
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c8 = 8 * q;
+        const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+      }
+      const unsigned wso = (unsigned)(q * 18 * CoutP * 16);
+      float4* dst = smem + b * BUF4;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ohb = oh0 + 8 * m + 2 * wv, owb = ow0 + 4 * hl;
-        long pix0;
-        if (a.ps_out) pix0 = ((long)(n * 2 * a.OH) + 2 * ohb + pi) * (2 * a.OW) + 2 * owb + pj;
-        else pix0 = ((long)n * a.OH + ohb) * a.OW + owb;
-        float* yb = a.y + pix0 * a.y_ldc + a.y_coff + ch;
-        const float* r1b = has_r1 ? a.r1 + pix0 * a.r1_ldc + a.r1_coff + ch : nullptr;
-        const float* r2b = has_r2 ? a.r2 + pix0 * a.r2_ldc + a.r2_coff + ch : nullptr;
-        const float* mb = has_m ? a.mask + pix0 * a.m_ldc + a.m_coff + ch : nullptr;
+      for (int i0 = 0; i0 < NL; i0 += LB) {
+        f32x4 r[LB];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int rr = reg >> 3, cc = (reg & 3) + 8 * ((reg >> 2) & 1);
-          if (!interior && (ohb + rr >= a.OH || owb + cc >= a.OW)) continue;
-          float v = a.alpha * (acc[m][t][reg] + bz);
-          if (has_r1) v += a.beta1 * r1b[rr * r1_rs + cc * r1_cs];
-          if (has_r2) v += a.beta2 * r2b[rr * r2_rs + cc * r2_cs];
-          v = v > 0.f ? v : v * a.slope;
-          if (has_m) v *= (mb[rr * m_rs + cc * m_cs] > 0.f ? 1.f : a.mask_slope);
-          yb[rr * y_rs + cc * y_cs] = v;
+        for (int j = 0; j < LB; ++j) {
+          const int i = i0 + j;
+          if (i < NL)
+            r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i < NXL ? xrsrc : wrsrc, vo[i], i < NXL ? xso : wso, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int i = i0 + j;
+          if (i >= NL) continue;
+          float4 v = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
+          if (i < NXL) {
+            if (in_slope != 1.f) {
+              v.x = v.x > 0.f ? v.x : v.x * in_slope; v.y = v.y > 0.f ? v.y : v.y * in_slope;
+              v.z = v.z > 0.f ? v.z : v.z * in_slope; v.w = v.w > 0.f ? v.w : v.w * in_slope;
+            }
+            const int idx = lane + i * 64;
+            if (idx < G::NX4) dst[idx] = v;
+          } else {
+            const int idx = lane + (i - NXL) * 64;
+            if (idx < NW4) dst[G::NX4 + idx] = v;
+          }
         }
       }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+      if (q + 1 < nq) stage(q + 1, (q & 1) ^ 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- MFMA waves
+  f32x16 acc[MT][NTN];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+  const int apy = 2 * wv + (l32 >> 4), apx = l32 & 15;
+  const int abase = apy * G::IW + apx;
+  constexpr int AM = 8 * G::IW;
+  float4 av[2][MT], bv[2][NTN];
+  auto ld_frag = [&](int p, int b, int tap) {
+    const int r = tap / 3, s = tap - 3 * r;
+    const float4* xb = smem + b * BUF4 + abase * 2 + hl;
+    const float4* wb = smem + b * BUF4 + G::NX4 + hl * BN + l32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av[p][m] = xb[(m * AM + r * G::IW + s) * 2];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) bv[p][t] = wb[tap * 2 * BN + t * 32];
+  };
+  auto mfma_tap = [&](int p) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+          const float ae = e == 0 ? av[p][m].x : e == 1 ? av[p][m].y : e == 2 ? av[p][m].z : av[p][m].w;
+          const float be = e == 0 ? bv[p][t].x : e == 1 ? bv[p][t].y : e == 2 ? bv[p][t].z : bv[p][t].w;
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[m][t], 0, 0, 0);
+        }
+  };
+  __syncthreads();                               // chunk 0 staged by the loader
+  ld_frag(0, 0, 0);
+  for (int q = 0; q < nq; ++q) {
+    const int b = q & 1;
+    const bool more = q + 1 < nq;
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) {
+      ld_frag((tap + 1) & 1, b, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tap(tap & 1);
+    }
+    __syncthreads();                             // buffer b consumed (tap 8 is in registers); b^1 staged
+    if (more) ld_frag(1, b ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(0);                                 // tap 8
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[0][m] = av[1][m];
+#pragma unroll
+      for (int t = 0; t < NTN; ++t) bv[0][t] = bv[1][t];
     }
   }
-  SRK_STAMP_AT(4);
+  conv_epilogue<BN, MT>(a, acc, smem, n, oh0, ow0, n0, wv, lane);
 }
 
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
@@ -422,8 +599,24 @@ int launch_k(const srk_conv_args& a, hipStream_t st) {
 // The global->LDS DMA variant (DMA = true) is correct but measured SLOWER than register staging on gfx950
 // (80 vs 73.6 cycles per MFMA at one workgroup per CU: each buffer_load...lds piece costs the issuing MFMA wave
 // more issue time than a buffer_load + ds_write_b128 pair), so it is not dispatched.
+template <int BN, int MODE>
+int launch_lw(const srk_conv_args& a, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * 2);
+  const int CoutP = srk_round_up(a.Cout, 32);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)srk_div_up(CoutP, BN));
+  hipLaunchKernelGGL((conv3x3_f32_lw_kernel<BN, MODE>), grid, dim3(320), 0, st, a);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
+static int g_use_lw = -1;   // SRK_CONV_LW=0 disables the loader-wave kernels (A/B measurements)
+
 template <int BN, int S, int MODE, bool VEC, int MT>
 int launch(const srk_conv_args& a, hipStream_t st) {
+  if constexpr (S == 1 && VEC && MT == 2 && BN == 64 && MODE != SRK_IN_ZERO_UPSAMPLE) {
+    if (g_use_lw < 0) { const char* e = getenv("SRK_CONV_LW"); g_use_lw = (e && e[0] == '0') ? 0 : 1; }
+    if (g_use_lw) return launch_lw<BN, MODE>(a, st);
+  }
   return launch_k<BN, S, MODE, VEC, MT, false>(a, st);
 }
 

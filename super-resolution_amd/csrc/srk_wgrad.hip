@@ -79,21 +79,27 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
   int t_end = t_begin + B.tpb;
   if (t_end > B.total_tiles) t_end = B.total_tiles;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Staging plan: per tile every thread moves NDY float4 of DY and NXH float4 of the X halo.  The global loads
+  // of tile t+1 are issued right after the barrier that opens tile t and held in registers during its MFMAs
+  // (HBM/L2 latency hidden); they are written to LDS between the two barriers that separate the tiles.
+  constexpr int NDY = (G::TP * 16 + SRK_THREADS - 1) / SRK_THREADS;
+  constexpr int NXH = (G::NHP * 16 + SRK_THREADS - 1) / SRK_THREADS;
+  float4 rdy[NDY], rxh[NXH];
+  auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % B.tilesW; tt /= B.tilesW;
     const int ty = tt % B.tilesH; tt /= B.tilesH;
     const int n = tt;
     const int oh0 = ty * G::TH, ow0 = tx * WTW;
     const int ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;
-
-    // ---- stage DY tile
-    for (int idx = tid; idx < G::TP * 16; idx += SRK_THREADS) {
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = tid + u * SRK_THREADS;
       const int px = idx >> 4, c4 = idx & 15;
       const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
       const int co = cout0 + 4 * c4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oh < B.OH && ow < B.OW && co < a.Cout) {
+      if (idx < G::TP * 16 && oh < B.OH && ow < B.OW && co < a.Cout) {
         const float* src;
         if (DYMODE == SRK_IN_UNSHUFFLE) {
           const int ij = co / Cps, c = co - ij * Cps;
@@ -110,16 +116,17 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
           if (co + 3 < a.Cout) v.w = src[3];
         }
       }
-      reinterpret_cast<float4*>(dys)[idx] = v;
+      rdy[u] = v;
     }
-    // ---- stage X halo
-    for (int idx = tid; idx < G::NHP * 16; idx += SRK_THREADS) {
+#pragma unroll
+    for (int u = 0; u < NXH; ++u) {
+      const int idx = tid + u * SRK_THREADS;
       const int hp = idx >> 4, c4 = idx & 15;
       const int hy = hp / G::IW, hx = hp - hy * G::IW;
       const int ih = ih0 + hy, iw = iw0 + hx;
       const int ci = cin0 + 4 * c4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
+      if (idx < G::NHP * 16 && ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
         const float* src = a.x + ((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff + ci;
         if (VEC) {
           v = *reinterpret_cast<const float4*>(src);
@@ -130,28 +137,60 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
           if (ci + 3 < a.Cin) v.w = src[3];
         }
       }
+      rxh[u] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = tid + u * SRK_THREADS;
+      if (idx < G::TP * 16) reinterpret_cast<float4*>(dys)[idx] = rdy[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NXH; ++u) {
+      const int idx = tid + u * SRK_THREADS;
+      float4 v = rxh[u];
       if (in_slope != 1.f) {
         v.x = v.x > 0.f ? v.x : v.x * in_slope; v.y = v.y > 0.f ? v.y : v.y * in_slope;
         v.z = v.z > 0.f ? v.z : v.z * in_slope; v.w = v.w > 0.f ? v.w : v.w * in_slope;
       }
-      reinterpret_cast<float4*>(xs)[idx] = v;
+      if (idx < G::NHP * 16) reinterpret_cast<float4*>(xs)[idx] = v;
     }
+  };
+
+  // per-lane LDS bases; inside a tile every k-step is a compile-time offset from them (pixel 2kk + hl)
+  const float* abase = dys + hl * 64 + 32 * wa + l32;
+  const float* bbase = xs + (hl * S) * 64 + 32 * wb + l32;
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    store_tile();
     __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
 
     if (active) {
-#pragma unroll 2
-      for (int kk = 0; kk < G::TP / 2; ++kk) {
-        const int px = 2 * kk + hl;
-        const int py = px / WTW, pxx = px % WTW;
-        const float av = dys[px * 64 + 32 * wa + l32];
-        if (do_bias) bsum += av;
-        const float* xrow = xs + ((py * S) * G::IW + pxx * S) * 64 + 32 * wb + l32;
+      // software-pipelined k-steps: operands of k-step kk+1 are read from LDS before the 9 MFMAs of kk issue
+      float av[2], bv[2][9];
+      auto ld_k = [&](int p, int kk) {
+        const int py = kk / (WTW / 2), pc = kk % (WTW / 2);          // pixel 2kk + hl = (row py, col 2pc + hl)
+        av[p] = abase[(2 * kk) * 64];
+        const float* xr0 = bbase + ((py * S) * G::IW + 2 * pc * S) * 64;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int r = tap / 3, s = tap - 3 * r;
-          const float bv = xrow[(r * G::IW + s) * 64];
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+          bv[p][tap] = xr0[(r * G::IW + s) * 64];
         }
+      };
+      ld_k(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < G::TP / 2; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < G::TP / 2) ld_k(cur ^ 1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias) bsum += av[cur];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][tap], acc[tap], 0, 0, 0);
       }
     }
     __syncthreads();
