@@ -252,6 +252,78 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cin == 1 (the image-side convs: discriminator model.0, generator conv1; models.py:63,142 with channels=1).
+// dW[o][0][tap] = sum_px DY[px][o] * x[px + tap] has only 9*Cout outputs and one input plane, so the MFMA tiling
+// (64 cin columns) would be 98 % padding: this is a bandwidth-bound streaming reduction instead.  One thread per
+// output pixel (grid-stride), 16 output channels per grid.y slice: 144 + 16 FMAs per pixel in registers, then a
+// wave shuffle reduction, an LDS reduction over the 4 waves and a fixed-order second pass over the workgroups.
+constexpr int C1_CG = 16;                 // output channels per grid.y slice
+constexpr int C1_VALS = C1_CG * 10;       // 9 taps + bias per channel
+constexpr int C1_BLOCKS = 512;
+
+template <int S>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* part) {
+  const WProb& a = B.prob[0];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cg = blockIdx.y, co0 = cg * C1_CG;
+  float acc[C1_CG][9], bacc[C1_CG];
+#pragma unroll
+  for (int o = 0; o < C1_CG; ++o) { bacc[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[o][t] = 0.f; }
+  const long npix = (long)B.N * B.OH * B.OW;
+  for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
+    long t = p;
+    const int ow = (int)(t % B.OW); t /= B.OW;
+    const int oh = (int)(t % B.OH); t /= B.OH;
+    const int n = (int)t;
+    float xv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = oh * S + tap / 3 - 1, iw = ow * S + tap % 3 - 1;
+      float v = 0.f;
+      if (ih >= 0 && iw >= 0 && ih < B.H && iw < B.W) v = a.x[((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff];
+      xv[tap] = v > 0.f ? v : v * a.in_slope;
+    }
+    const float* dyp = a.dy + p * a.dy_ldc + a.dy_coff + co0;
+#pragma unroll
+    for (int o = 0; o < C1_CG; ++o) {
+      const float d = (co0 + o < a.Cout) ? dyp[o] : 0.f;
+      bacc[o] += d;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) acc[o][tap] += d * xv[tap];
+    }
+  }
+  __shared__ float red[4][C1_VALS];
+#pragma unroll
+  for (int o = 0; o < C1_CG; ++o) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      float v = t < 9 ? acc[o][t] : bacc[o];
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+      if (lane == 0) red[wv][o * 10 + t] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < C1_VALS)
+    part[((long)blockIdx.x * gridDim.y + cg) * C1_VALS + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ void wgrad_c1_reduce_kernel(const WBatch B, const float* __restrict__ part, int nblocks, int ngroups) {
+  const WProb& a = B.prob[0];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ngroups * C1_VALS) return;
+  const int cg = gid / C1_VALS, r = gid % C1_VALS, o = cg * C1_CG + r / 10, t = r % 10;
+  if (o >= a.Cout) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[((long)b * ngroups + cg) * C1_VALS + r];
+  s *= a.scale;
+  if (t < 9) { float* d = a.dw + o * 9 + t; *d = a.accumulate ? *d + s : s; }
+  else if (a.db) { float* d = a.db + o; *d = a.accumulate ? *d + s : s; }
+}
+
 int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (!args || n <= 0 || n > MAX_PROB) return SRK_ERR_BAD_ARG;
   const srk_wgrad_args& a0 = args[0];
@@ -284,13 +356,20 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   B.total_tiles = a0.N * B.tilesH * B.tilesW;
   int target = 512 / nc;
   if (target < 1) target = 1;
+  // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
+  // split finer than 8 tiles per workgroup
+  const int maxP = B.total_tiles / 8 > 0 ? B.total_tiles / 8 : 1;
+  if (target > maxP) target = maxP;
   int P = B.total_tiles < target ? B.total_tiles : target;
   B.tpb = srk_div_up(B.total_tiles, P);
   B.P = srk_div_up(B.total_tiles, B.tpb);
   return SRK_OK;
 }
 
+bool use_c1(const WBatch& B) { return B.n_prob == 1 && B.prob[0].Cin == 1 && B.dy_mode == SRK_IN_PLAIN; }
+
 size_t ws_bytes(const WBatch& B) {
+  if (use_c1(B)) return (size_t)C1_BLOCKS * srk_div_up(B.prob[0].Cout, C1_CG) * C1_VALS * sizeof(float);
   return ((size_t)B.P * B.n_chunks * CHUNK_FLOATS + (size_t)B.P * B.n_chunks * 64) * sizeof(float);
 }
 
@@ -329,6 +408,18 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
   float* part = (float*)a0.workspace;
   float* pbias = part + (size_t)B.P * B.n_chunks * CHUNK_FLOATS;
   hipStream_t st = (hipStream_t)stream;
+  if (use_c1(B)) {
+    const int ngroups = srk_div_up(a0.Cout, C1_CG);
+    const long npix = (long)a0.N * a0.OH * a0.OW;
+    int nblocks = (int)((npix + 255) / 256);
+    if (nblocks > C1_BLOCKS) nblocks = C1_BLOCKS;
+    if (a0.stride == 1) hipLaunchKernelGGL(wgrad_c1_kernel<1>, dim3(nblocks, ngroups), dim3(256), 0, st, B, part);
+    else hipLaunchKernelGGL(wgrad_c1_kernel<2>, dim3(nblocks, ngroups), dim3(256), 0, st, B, part);
+    SRK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((ngroups * C1_VALS + 255) / 256), dim3(256), 0, st, B, (const float*)part, nblocks, ngroups);
+    SRK_CHECK_LAUNCH();
+    return SRK_OK;
+  }
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
   if (a0.dy_mode == SRK_IN_UNSHUFFLE) {

@@ -19,13 +19,25 @@ from ._lib import View
 
 
 def _pack(w: torch.Tensor, transpose: bool):
+    """OIHW weight -> packed fragment order (forward or transposed/flipped for the data gradient).  A Parameter is
+    packed once per version (the cache lives ON the Parameter object, so a new module can never see a stale entry):
+    the discriminator weights change once per iteration but are used by ~13 passes
+    (esrgan.py:493-494,569-570,601 + their backward passes)."""
     co, ci = w.shape[:2]
-    w = w.detach().contiguous()
+    cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable:
+        cache = w.__dict__.setdefault("_srk_pack", {})
+        hit = cache.get(transpose)
+        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+            return hit[2]
+    wd = w.detach().contiguous()
     K, M = (co, ci) if transpose else (ci, co)
     dst = torch.empty(L.packed_floats(K, M), dtype=torch.float32, device=w.device)
     t = L.PackTable(w.device)
-    t.add(w, dst, M=M, k_off=0, k_len=K, K_total=K, transpose=transpose)
+    t.add(wd, dst, M=M, k_off=0, k_len=K, K_total=K, transpose=transpose)
     t.run()
+    if cacheable:
+        cache[transpose] = (w._version, w.data_ptr(), dst)
     return dst
 
 
