@@ -5,9 +5,11 @@
 
 A "step" is one pass of the hot path over one synthetic batch of jet images (64x64 LR -> 256x256 HR,
 GeneratorRRDB(1, 64, 23, num_upsample=2)):
-  g_only : the reference's warm-up iteration (esrgan.py:416-439): G forward, L1, backward, Adam  (BASELINE configs[1])
-  gan    : full iteration (esrgan.py:457-626): G phase through two patch discriminators + D phase with
-           relativistic BCE and gradient penalty, three Adam steps                             (BASELINE configs[2])
+  gan    : (default; BASELINE.json's metric "G+D step") full iteration, esrgan.py:457-626: G phase through two
+           patch discriminators + D phase with relativistic BCE and gradient penalty, three Adam steps, batch 32/GPU
+           (BASELINE configs[2]; configs[3] = the same on 8 GPUs)
+  g_only : the reference's warm-up iteration (esrgan.py:416-439): G forward, L1, backward, Adam, batch 16/GPU
+           (BASELINE configs[1])
 Inputs are generated on the GPU before the timed region.  For N > 1 launch with
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: one process per GPU, weak scaling
 (fixed per-GPU batch), gradients averaged with RCCL all-reduce overlapped with the backward pass.
@@ -36,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("SRK_WORKLOAD", "g_only"), choices=["g_only", "gan"])
+    ap.add_argument("--workload", default=os.environ.get("SRK_WORKLOAD", "gan"), choices=["g_only", "gan"],
+                    help="gan = BASELINE.json's metric (full G+D iteration, configs[2]); g_only = warm-up iteration (configs[1])")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
     ap.add_argument("--res-blocks", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
