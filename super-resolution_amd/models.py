@@ -110,6 +110,7 @@ class GeneratorRRDB(nn.Module):
         self.power = nn.Parameter(torch.Tensor([power]), False)
         self.multiplier = nn.Parameter(torch.Tensor([multiplier]), False)
         self._scalars = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_scalars", None))
         self._engine = GeneratorEngine(self)
         if uniform_init:
             self.init_conv2d()
@@ -176,13 +177,22 @@ class Markovian_Discriminator(nn.Module):
         layers.append(Conv3x3(in_filters, 1, kernel_size=3, stride=1, padding=1))
         self.output_shape = (1, patch_h, patch_w)
         self.model = nn.Sequential(*layers)
+        self._packed = None
 
     def forward(self, img, *args):
+        convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
+        if self._packed is None or len(self._packed.convs) != len(convs):
+            self._packed = ops.PackedConvs(convs)
+        need_bwd = torch.is_grad_enabled() and (img.requires_grad or any(c.weight.requires_grad for c in convs))
+        self._packed.refresh(need_bwd)
         z = ops.to_nhwc(img.float())
         in_slope = 1.0
+        ci = 0
         for m in self.model:
             if isinstance(m, nn.Conv2d):
-                z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope)
+                z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope, self._packed.fwd[ci],
+                                 self._packed.bwd[ci] if need_bwd else None)
+                ci += 1
                 in_slope = 1.0
             elif isinstance(m, nn.LeakyReLU):
                 in_slope = m.negative_slope        # applied while the next conv stages its input

@@ -19,26 +19,51 @@ from ._lib import View
 
 
 def _pack(w: torch.Tensor, transpose: bool):
-    """OIHW weight -> packed fragment order (forward or transposed/flipped for the data gradient).  A Parameter is
-    packed once per version (the cache lives ON the Parameter object, so a new module can never see a stale entry):
-    the discriminator weights change once per iteration but are used by ~13 passes
-    (esrgan.py:493-494,569-570,601 + their backward passes)."""
+    """OIHW weight -> packed fragment order (forward, or transposed + tap-flipped for the data gradient).
+    Always packs from the current values: ``Parameter._version`` cannot be used as a cache key (fused Adam updates
+    parameters without bumping it), so callers that reuse weights pass pre-packed tensors explicitly (PackedConvs)."""
     co, ci = w.shape[:2]
-    cacheable = isinstance(w, torch.nn.Parameter)
-    if cacheable:
-        cache = w.__dict__.setdefault("_srk_pack", {})
-        hit = cache.get(transpose)
-        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
-            return hit[2]
     wd = w.detach().contiguous()
     K, M = (co, ci) if transpose else (ci, co)
     dst = torch.empty(L.packed_floats(K, M), dtype=torch.float32, device=w.device)
     t = L.PackTable(w.device)
     t.add(wd, dst, M=M, k_off=0, k_len=K, K_total=K, transpose=transpose)
     t.run()
-    if cacheable:
-        cache[transpose] = (w._version, w.data_ptr(), dst)
     return dst
+
+
+class PackedConvs:
+    """Forward and data-gradient packings of a list of conv weights, each refreshed with ONE launch.  A module calls
+    ``refresh()`` at the top of every forward (weights cannot change between a forward and its backward), so one
+    discriminator pass costs 2 pack launches instead of one per conv call."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self._sig = None
+
+    def _build(self):
+        dev = self.convs[0].weight.device
+        self.fwd, self.bwd = [], []
+        self.tab_f, self.tab_b = L.PackTable(dev), L.PackTable(dev)
+        for c in self.convs:
+            co, ci = c.weight.shape[:2]
+            f = torch.empty(L.packed_floats(ci, co), dtype=torch.float32, device=dev)
+            b = torch.empty(L.packed_floats(co, ci), dtype=torch.float32, device=dev)
+            self.tab_f.add(c.weight.data, f, M=co, k_off=0, k_len=ci, K_total=ci)
+            self.tab_b.add(c.weight.data, b, M=ci, k_off=0, k_len=co, K_total=co, transpose=True)
+            self.fwd.append(f)
+            self.bwd.append(b)
+        self.tab_f.finalize()
+        self.tab_b.finalize()
+
+    def refresh(self, need_bwd: bool):
+        sig = tuple(c.weight.data_ptr() for c in self.convs)
+        if sig != self._sig:
+            self._build()
+            self._sig = sig
+        self.tab_f.run()
+        if need_bwd:
+            self.tab_b.run()
 
 
 def _out_hw(h, w, stride):
@@ -50,27 +75,28 @@ def _require_gpu(t):
         raise RuntimeError("super-resolution_amd: convolution kernels only run on a ROCm GPU tensor (no CPU fallback)")
 
 
-def conv_pre_raw(x, w, b, stride, in_slope):
+def conv_pre_raw(x, w, b, stride, in_slope, wp=None):
     _require_gpu(x)
     N, H, W, Ci = x.shape
     Co = w.shape[0]
     OH, OW = _out_hw(H, W, stride)
     y = torch.empty(N, OH, OW, Co, dtype=torch.float32, device=x.device)
-    L.conv3x3(View(x), _pack(w, False), None if b is None else b.detach().contiguous(), View(y), N=N, H=H, W=W, OH=OH, OW=OW,
+    L.conv3x3(View(x), wp if wp is not None else _pack(w, False), None if b is None else b.detach().contiguous(), View(y), N=N, H=H, W=W, OH=OH, OW=OW,
               Cin=Ci, Cout=Co, stride=stride, in_slope=in_slope)
     return y
 
 
-def conv_dgrad_raw(dz, w, x_or_none, stride, in_slope, H, W):
+def conv_dgrad_raw(dz, w, x_or_none, stride, in_slope, H, W, wpt=None):
     _require_gpu(dz)
+    wpt = wpt if wpt is not None else _pack(w, True)
     N, OH, OW, Co = dz.shape
     Ci = w.shape[1]
     dx = torch.empty(N, H, W, Ci, dtype=torch.float32, device=dz.device)
     mask = View(x_or_none) if (x_or_none is not None and in_slope != 1.0) else None
     if stride == 1:
-        L.conv3x3(View(dz), _pack(w, True), None, View(dx), N=N, H=H, W=W, OH=H, OW=W, Cin=Co, Cout=Ci, mask=mask, mask_slope=in_slope)
+        L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=H, W=W, OH=H, OW=W, Cin=Co, Cout=Ci, mask=mask, mask_slope=in_slope)
     else:
-        L.conv3x3(View(dz), _pack(w, True), None, View(dx), N=N, H=OH, W=OW, OH=H, OW=W, Cin=Co, Cout=Ci,
+        L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=OH, W=OW, OH=H, OW=W, Cin=Co, Cout=Ci,
                   in_mode=L.IN_ZERO_UPSAMPLE, mask=mask, mask_slope=in_slope)
     return dx
 
@@ -87,11 +113,12 @@ def conv_wgrad_raw(x, dz, stride, in_slope, want_bias=True):
 
 class ConvPre(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, in_slope):
+    def forward(ctx, x, w, b, stride, in_slope, wp=None, wpt=None):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.in_slope, ctx.has_b = stride, in_slope, b is not None
-        return conv_pre_raw(x, w, b, stride, in_slope)
+        ctx.wp, ctx.wpt = wp, wpt
+        return conv_pre_raw(x, w, b, stride, in_slope, wp)
 
     @staticmethod
     def backward(ctx, dz):
@@ -99,21 +126,22 @@ class ConvPre(torch.autograd.Function):
         dz = dz.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ConvDgrad.apply(dz, w, x, ctx.stride, ctx.in_slope)
+            dx = ConvDgrad.apply(dz, w, x, ctx.stride, ctx.in_slope, ctx.wp, ctx.wpt)
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dw, db = ConvWgrad.apply(x, dz, ctx.stride, ctx.in_slope)
             if not ctx.has_b:
                 db = None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class ConvDgrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dz, w, x, stride, in_slope):
+    def forward(ctx, dz, w, x, stride, in_slope, wp=None, wpt=None):
         dz = dz.contiguous()
         ctx.save_for_backward(dz, w, x)
         ctx.stride, ctx.in_slope = stride, in_slope
-        return conv_dgrad_raw(dz, w, x, stride, in_slope, x.shape[1], x.shape[2])
+        ctx.wp = wp
+        return conv_dgrad_raw(dz, w, x, stride, in_slope, x.shape[1], x.shape[2], wpt)
 
     @staticmethod
     def backward(ctx, gdx):
@@ -124,10 +152,10 @@ class ConvDgrad(torch.autograd.Function):
             t = torch.where(x > 0, t, t * s)          # lrelu' is piecewise constant: no gradient to x
         g_dz = g_w = None
         if ctx.needs_input_grad[0]:
-            g_dz = ConvPre.apply(t, w, None, ctx.stride, 1.0)
+            g_dz = ConvPre.apply(t, w, None, ctx.stride, 1.0, ctx.wp, None)
         if ctx.needs_input_grad[1]:
             g_w, _ = ConvWgrad.apply(t, dz, ctx.stride, 1.0)
-        return g_dz, g_w, None, None, None
+        return g_dz, g_w, None, None, None, None, None
 
 
 class ConvWgrad(torch.autograd.Function):
@@ -153,9 +181,10 @@ class ConvWgrad(torch.autograd.Function):
         return g_x, g_dz, None, None
 
 
-def conv_pre(x, w, b, stride=1, in_slope=1.0):
-    """z = conv3x3(lrelu_{in_slope}(x), w, stride, pad 1) + b on an NHWC tensor; differentiable twice."""
-    return ConvPre.apply(x, w, b, stride, in_slope)
+def conv_pre(x, w, b, stride=1, in_slope=1.0, wp=None, wpt=None):
+    """z = conv3x3(lrelu_{in_slope}(x), w, stride, pad 1) + b on an NHWC tensor; differentiable twice.
+    ``wp`` / ``wpt``: optional pre-packed forward / data-gradient weights (PackedConvs) of ``w``."""
+    return ConvPre.apply(x, w, b, stride, in_slope, wp, wpt)
 
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:

@@ -159,3 +159,25 @@ def test_cpu_tensor_fails_loudly(srk):
     gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1)
     with pytest.raises(RuntimeError):
         gen(torch.rand(1, 1, 8, 8))
+
+
+def test_weights_updated_by_fused_adam_are_never_stale(srk):
+    """Fused Adam updates parameters WITHOUT bumping Parameter._version, so nothing may cache packed weights by
+    version: after an optimizer step the very next forward must use the new values (G and D)."""
+    D = srk.Markovian_Discriminator((1, 32, 32), [16, 32, 32, 64]).cuda()
+    _load_closed_form(D, gain=2.0)
+    gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1).cuda()
+    _load_closed_form(gen)
+    x = torch.rand(2, 1, 32, 32, device="cuda")
+    xl = torch.rand(2, 1, 16, 16, device="cuda")
+    for mod, inp in ((D, x), (gen, xl)):
+        opt = torch.optim.Adam([p for p in mod.parameters() if p.requires_grad], lr=1e-2, fused=True)
+        y0 = mod(inp)
+        y0.square().mean().backward()
+        opt.step()
+        with torch.no_grad():
+            y1 = mod(inp)
+        sd = {k: v.cpu() for k, v in mod.state_dict().items()}
+        ref = O.discriminator_forward(sd, inp.cpu()) if mod is D else O.generator_forward(sd, inp.cpu(), 1, 1, 0.2, training=True)[0]
+        assert rel(y1.cpu(), ref) < OUT_TOL
+        assert (y1 - y0.detach()).abs().max().item() > 1e-3

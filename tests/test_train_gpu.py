@@ -116,3 +116,45 @@ def test_esrgan_train_entrypoint_checkpoint_roundtrip(tmp_path):
     assert (mp / "t_generator_2_continued.pth").exists() and (mp / "t_discriminator_pow_2_continued.pth").exists()
     with pytest.raises(NotImplementedError):
         es.train(es.options(lambda_hist=1.0))
+
+
+def test_G8_reference_train_trajectory(golden_dir):
+    """Replays the loss trajectory recorded from the reference's own esrgan.train() (tools/make_golden_train.py):
+    2 warm-up + 4 GAN iterations with Adam updates of G, D_def and D_pow, d_threshold gating and the recorded
+    gradient-penalty epsilons.  Later iterations depend on every earlier update, so this pins the whole step."""
+    import numpy as np
+    d = np.load(os.path.join(golden_dir, "G8_train_trajectory.npz"))
+    hr, factor, R, batch, warm = [int(v) for v in d["cfg"]]
+    train = importlib.import_module("super-resolution_amd.train")
+    st = train.Stepper(workload="gan", res_blocks=R, filters=64, device=torch.device("cuda"), hr=hr, factor=factor, res_scale=0.1)
+    st.generator.load_state_dict(O.closed_form_fill({k: v.cpu() for k, v in st.generator.state_dict().items()}))
+    for k, D in st.discriminators.items():
+        D.load_state_dict(O.closed_form_fill({n: v.cpu() for n, v in D.state_dict().items()}, gain=2.0 + k))
+    lr_b, hr_b, eps = torch.from_numpy(d["lr"]), torch.from_numpy(d["hr"]), torch.from_numpy(d["eps"])
+    n_it = len(d["loss.g_loss"])
+    got = {k: [] for k in ("g_loss", "d_loss_def", "d_loss_pow", "adv_loss", "adv_loss_pow", "pixel_loss_pow", "lr_loss")}
+    gan_i = 0
+    for it in range(n_it):
+        x, y = lr_b[it].cuda(), hr_b[it].cuda()
+        if it < warm:
+            out = st.warmup_step(x, y)
+            got["g_loss"].append(out["g_loss"].item())
+        else:
+            out = st.gan_step(x, y, epsilons={0: eps[2 * gan_i].cuda(), 1: eps[2 * gan_i + 1].cuda()})
+            v = st.loss_scalars(out)
+            for k in got:
+                got[k].append(v[k])
+            gan_i += 1
+    # Tolerance grows with the iteration index: Adam's first updates are ~lr*sign(g), so gradient entries at
+    # fp32-noise level (e.g. the final D bias, exactly 0 in the reference, 6e-8 here from a different summation
+    # order) move a weight by +-lr instead of 0 and the GAN dynamics amplify that (measured here: 1e-7 at the first
+    # GAN iteration, 8e-4 at the second, 3e-2 at the third).  A wrong step semantics is off by O(1) from iteration 0.
+    for k in got:
+        ref = d["loss." + k]
+        mine = np.array(got[k])
+        assert mine.shape == ref.shape, k
+        n = len(ref)
+        first_gan = n - 4                      # index of the first GAN iteration in this series
+        for i in range(n):
+            tol = 2e-5 if i <= first_gan else (3e-3 if i == first_gan + 1 else 8e-2)
+            assert abs(mine[i] - ref[i]) <= tol * max(1.0, abs(ref[i])), (k, i, mine, ref)

@@ -11,6 +11,7 @@ Weights are closed-form (oracle.closed_form_fill) so they need no storage.
 """
 import os
 import sys
+sys.dont_write_bytecode = True   # importing the reference must not leave __pycache__ inside /root/reference
 import math
 import numpy as np
 import torch
