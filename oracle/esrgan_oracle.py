@@ -295,3 +295,18 @@ def d_phase_loss(d_sd: dict, gt: Tensor, gen_detached: Tensor, epsilon: Optional
         gp = ((grads.norm(2, dim=1) - 1) ** 2).mean() * lambda_reg / 2
         loss_D = loss_D + gp
     return loss_D, gp
+
+
+# --------------------------------------------------------------------------- eval-mode metrics
+def calculate_metrics(sd, batches, num_res_blocks, num_upsample, res_scale, factor):
+    """HR/LR L1 part of evaluation/eval.py:455-494 (no EMD): eval-mode forward, SumPool, per-image L1 means, and the
+    reference's key assignment (eval.py:491 zips ['hr_l1','lr_l1'] with [lr_similarity, hr_similarity])."""
+    import numpy as np
+    lr_sim, hr_sim = [], []
+    with torch.no_grad():
+        for lr, hr in batches:
+            gen_hr, _ = generator_forward(sd, lr, num_res_blocks, num_upsample, res_scale, training=False)
+            gen_lr = sum_pool(gen_hr, factor)
+            lr_sim.extend((gen_lr - lr).abs().numpy().mean((1, 2, 3)).tolist())
+            hr_sim.extend((gen_hr - hr).abs().numpy().mean((1, 2, 3)).tolist())
+    return {n: {"mean": float(np.mean(v)), "std": float(np.std(v))} for n, v in zip(["hr_l1", "lr_l1"], [lr_sim, hr_sim])}
