@@ -76,6 +76,9 @@ typedef struct srk_conv_args {
   const float* r2; int32_t r2_ldc, r2_coff; float beta2;
   float slope;
   const float* mask; int32_t m_ldc, m_coff; float mask_slope;
+  int32_t wp_format;        /* 0: fp32 fragments, exact-fp32 MFMA (default).  1: split-bf16 ("bf16x3") fragments from
+                               srk_pack_weights_bf16x3 -> 3 bf16 MFMAs per product, fp32 accumulate, ~2^-16 relative
+                               operand precision; opt-in, needs srk_conv3x3_bf16x3_supported() */
 } srk_conv_args;
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
@@ -133,6 +136,8 @@ typedef struct srk_pack_entry {
   int32_t K_total;          /* total K of dst (for zero fill of the tail chunk) */
   int32_t ps;
   float scale;
+  int32_t fmt;              /* 0: fp32 fragments [K/8][tap][h][Mp][4];  1: split bf16 [K/16][tap][hi|lo][h][Mp][8]
+                               (same byte size; k_off % 16 == 0).  One table = one format. */
   int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
 } srk_pack_entry;
 
@@ -140,7 +145,11 @@ typedef struct srk_pack_entry {
 int srk_pack_plan(srk_pack_entry* host_entries, int n, int64_t* total);
 /* device_entries: the same table copied to device memory by the caller */
 int srk_pack_weights(const srk_pack_entry* device_entries, int n, int64_t total, void* stream);
-size_t srk_packed_floats(int K, int M);
+/* the same for a table whose entries have fmt == 1 */
+int srk_pack_weights_bf16x3(const srk_pack_entry* device_entries, int n, int64_t total, void* stream);
+size_t srk_packed_floats(int K, int M);   /* rounds K up to 16: valid for both formats */
+/* 1 if srk_conv3x3 accepts wp_format == 1 for this geometry (stride 1, Cin % 16 == 0, 16-byte addressable input) */
+int srk_conv3x3_bf16x3_supported(const srk_conv_args* a);
 
 /* Standalone nn.PixelShuffle(2) forward / backward on NHWC (models.py:89); C = channels of the
  * shuffled tensor, x is [N,H,W,4C] in OIHW channel order (c*4 + 2i + j), y is [N,2H,2W,C]. */

@@ -17,7 +17,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
-    "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
+    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_strerror", "srk_version",
 ]
 
@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("r2", _fp), ("r2_ldc", C.c_int32), ("r2_coff", C.c_int32), ("beta2", C.c_float),
         ("slope", C.c_float),
         ("mask", _fp), ("m_ldc", C.c_int32), ("m_coff", C.c_int32), ("mask_slope", C.c_float),
+        ("wp_format", C.c_int32),
     ]
 
 
@@ -54,7 +55,7 @@ class PackEntry(C.Structure):
     _fields_ = [
         ("src", _fp), ("dst", _fp), ("src_cout", C.c_int32), ("src_cin", C.c_int32), ("transpose", C.c_int32),
         ("c_begin", C.c_int32), ("M", C.c_int32), ("k_off", C.c_int32), ("k_len", C.c_int32), ("K_total", C.c_int32),
-        ("ps", C.c_int32), ("scale", C.c_float), ("elem_begin", C.c_int64),
+        ("ps", C.c_int32), ("scale", C.c_float), ("fmt", C.c_int32), ("elem_begin", C.c_int64),
     ]
 
 
@@ -82,6 +83,8 @@ def lib():
         L.srk_conv3x3_wgrad_batched_workspace.argtypes = [C.POINTER(WgradArgs), C.c_int, C.POINTER(C.c_size_t)]
         L.srk_pack_plan.argtypes = [C.POINTER(PackEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_pack_weights.argtypes = [_fp, C.c_int, C.c_int64, _fp]
+        L.srk_pack_weights_bf16x3.argtypes = [_fp, C.c_int, C.c_int64, _fp]
+        L.srk_conv3x3_bf16x3_supported.argtypes = [C.POINTER(ConvArgs)]
         for name in ("srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd"):
             getattr(L, name).argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
         L.srk_nchw_to_nhwc.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
@@ -152,6 +155,8 @@ class KernelTimer:
 
 def _conv_kernel_name(a) -> str:
     """Mirror of the dispatch in srk_conv.hip (srk_conv3x3)."""
+    if a.wp_format == 1:
+        return f"conv3x3_bf16x3_kernel<{a.in_mode}>"
     vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
     bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
     mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
@@ -163,9 +168,10 @@ def _conv_kernel_name(a) -> str:
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
             ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
-            mask: View = None, mask_slope=1.0, in_slope=1.0):
+            mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0):
     a = ConvArgs()
     a.in_slope = in_slope
+    a.wp_format = getattr(wp, "fmt", wp_format)
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout = N, H, W, OH, OW, Cin, Cout
     a.stride, a.in_mode, a.ps_out = stride, in_mode, int(ps_out)
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
@@ -255,8 +261,9 @@ def packed_floats(K: int, M: int) -> int:
 class PackTable:
     """A batch of weight-packing jobs executed by ONE kernel launch (srk_pack_weights)."""
 
-    def __init__(self, device):
+    def __init__(self, device, fmt=0):
         self.device = device
+        self.fmt = fmt               # 0: fp32 fragments, 1: split-bf16 fragments (one table = one format)
         self.entries = []
         self._dev = None
         self._total = 0
@@ -267,12 +274,14 @@ class PackTable:
         e.src, e.dst = src.data_ptr(), dst.data_ptr()
         e.src_cout, e.src_cin = src.shape[0], src.shape[1]
         e.transpose, e.c_begin, e.M, e.k_off, e.k_len, e.K_total = int(transpose), c_begin, M, k_off, k_len, K_total
-        e.ps, e.scale = int(ps), scale
+        e.ps, e.scale, e.fmt = int(ps), scale, self.fmt
         self.entries.append(e)
         self._dev = None
 
     def finalize(self):
         n = len(self.entries)
+        if n == 0:
+            return
         arr = (PackEntry * n)(*self.entries)
         total = C.c_int64(0)
         check(lib().srk_pack_plan(arr, n, C.byref(total)), "srk_pack_plan")
@@ -282,9 +291,12 @@ class PackTable:
         self._n = n
 
     def run(self):
+        if not self.entries:
+            return
         if self._dev is None:
             self.finalize()
-        check(lib().srk_pack_weights(self._dev.data_ptr(), self._n, self._total, stream_ptr()), "srk_pack_weights")
+        fn = lib().srk_pack_weights_bf16x3 if self.fmt == 1 else lib().srk_pack_weights
+        check(fn(self._dev.data_ptr(), self._n, self._total, stream_ptr()), "srk_pack_weights")
 
 
 def pixel_shuffle_fwd(x, y, N, H, W, C_):

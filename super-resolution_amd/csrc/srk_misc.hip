@@ -136,7 +136,7 @@ inline unsigned grid_for(long total, int block = 256) {
 }  // namespace
 
 extern "C" size_t srk_packed_floats(int K, int M) {
-  return (size_t)srk_div_up(K, 8) * 9 * 2 * srk_round_up(M, 32) * 4;
+  return (size_t)srk_div_up(K, 16) * 2 * 9 * 2 * srk_round_up(M, 32) * 4;
 }
 
 extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
@@ -145,10 +145,14 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
     e[i].elem_begin = acc;
     // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
+    const int ck = e[i].fmt == 1 ? 16 : 8;
     int k_end = e[i].k_off + e[i].k_len;
-    int nq = srk_div_up(k_end, 8) - (e[i].k_off >> 3);
+    int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
+    // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
     acc += (int64_t)nq * 9 * 2 * srk_round_up(e[i].M, 32);
   }
   *total = acc;
@@ -160,6 +164,12 @@ extern "C" int srk_pack_weights(const srk_pack_entry* dev, int n, int64_t total,
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dev, n, (long)total);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
+}
+
+int srk_launch_pack_bf16x3(const srk_pack_entry* dev, int n, int64_t total, hipStream_t st);
+extern "C" int srk_pack_weights_bf16x3(const srk_pack_entry* dev, int n, int64_t total, void* stream) {
+  if (!dev || n <= 0 || total <= 0) return SRK_ERR_BAD_ARG;
+  return srk_launch_pack_bf16x3(dev, n, total, (hipStream_t)stream);
 }
 
 extern "C" int srk_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -47,6 +47,17 @@ class _Flat:
             off += n
 
 
+class _PackedW:
+    """A packed weight slice plus the fragment format it was packed in (read by _lib.conv3x3)."""
+    __slots__ = ("t", "fmt")
+
+    def __init__(self, t, fmt):
+        self.t, self.fmt = t, fmt
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
 class DrbPack:
     """Packed weights of one DenseResidualBlock: forward convs k=1..5 and backward convs m=4..0."""
 
@@ -64,6 +75,9 @@ class GeneratorEngine:
         self._sig = None
         self._sync = False
         self._grad_scale = 1.0
+        # "f32": exact-fp32 MFMA everywhere (default).  "bf16x3": forward / data-gradient convs whose K is a multiple
+        # of 16 run as 3 split-bf16 MFMAs per product (fp32 accumulate, ~2^-16 operand precision); opt-in.
+        self.precision = os.environ.get("SRK_PRECISION", "f32")
         self._side = None            # second HIP stream: weight-gradient kernels overlap the data-gradient chain
         self.overlap_wgrad = os.environ.get("SRK_OVERLAP_WGRAD", "0") != "0"   # measured +1.2 % only; off keeps per-kernel timing clean
 
@@ -151,16 +165,25 @@ class GeneratorEngine:
         g = self.gen
         F_, C_ = g.filters, g.channels
         self.flat_f, self.flat_b = _Flat(), _Flat()
-        self.tab_f, self.tab_b = L.PackTable(device), L.PackTable(device)
+        # one table per (direction, fragment format)
+        self.tab_f, self.tab_b = [L.PackTable(device, 0), L.PackTable(device, 1)], [L.PackTable(device, 0), L.PackTable(device, 1)]
+        self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
+        bf = self.precision == "bf16x3"
+        self._built_precision = self.precision
+
+        def fmt_of(K, M):
+            return 1 if (bf and K % 16 == 0 and M >= 16) else 0
 
         def simple(name, conv, ps=False, need_bwd=True):
             co, ci = conv.weight.shape[:2]
             fi = self.flat_f.reserve(L.packed_floats(ci, co))
+            self.fmt_f[fi] = fmt_of(ci, co) if (not ps or (co // 4) % 4 == 0) else 0
             jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=ci, ps=ps)))
             bi = None
             if need_bwd:
                 bi = self.flat_b.reserve(L.packed_floats(co, ci))
+                self.fmt_b[bi] = fmt_of(co, ci) if (not ps or (co // 4) % 16 == 0) else 0
                 jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=co, transpose=True, ps=ps)))
             return fi, bi
 
@@ -169,10 +192,12 @@ class GeneratorEngine:
             for k in range(1, 6):
                 w = getattr(d, f"b{k}")[0].weight
                 p.fwd[k] = self.flat_f.reserve(L.packed_floats(k * F_, F_))
+                self.fmt_f[p.fwd[k]] = fmt_of(k * F_, F_)
                 jobs_f.append((w, p.fwd[k], dict(M=F_, k_off=0, k_len=k * F_, K_total=k * F_)))
             for m in range(0, 5):
                 K = (5 - m) * F_
                 p.bwd[m] = self.flat_b.reserve(L.packed_floats(K, F_))
+                self.fmt_b[p.bwd[m]] = fmt_of(K, F_) if F_ % 16 == 0 else 0
                 for k in range(5, m, -1):     # input slice (5-k) of the dy buffer carries dy_k
                     w = getattr(d, f"b{k}")[0].weight
                     jobs_b.append((w, p.bwd[m], dict(M=F_, k_off=(5 - k) * F_, k_len=F_, K_total=K, transpose=True,
@@ -198,11 +223,11 @@ class GeneratorEngine:
         self.flat_f.materialize(device)
         self.flat_b.materialize(device)
         for w, fi, kw in jobs_f:
-            self.tab_f.add(w.data, self.flat_f.slices[fi], **kw)
+            self.tab_f[self.fmt_f[fi]].add(w.data, self.flat_f.slices[fi], **kw)
         for w, bi, kw in jobs_b:
-            self.tab_b.add(w.data, self.flat_b.slices[bi], **kw)
-        self.tab_f.finalize()
-        self.tab_b.finalize()
+            self.tab_b[self.fmt_b[bi]].add(w.data, self.flat_b.slices[bi], **kw)
+        for t in self.tab_f + self.tab_b:
+            t.finalize()
 
     def _ensure_packed(self, need_bwd: bool):
         """(Re)pack the weights.  The canonical OIHW Parameters stay the source of truth (optimizer steps,
@@ -210,14 +235,16 @@ class GeneratorEngine:
         is simply redone on every forward (fwd table) / backward (bwd table) instead of tracking versions."""
         ps = self.params()
         dev = ps[0].device
-        sig = (dev, tuple(p.data_ptr() for p in ps))
+        sig = (dev, self.precision, tuple(p.data_ptr() for p in ps))
         if sig != self._sig:
             self._build_tables(dev)
             self._sig = sig
         if need_bwd:
-            self.tab_b.run()
+            for t in self.tab_b:
+                t.run()
             return
-        self.tab_f.run()
+        for t in self.tab_f:
+            t.run()
         # packed-order biases of the PixelShuffle convs (o' = ij*F + c  <->  o = 4c + ij)
         self.ps_bias = {}
         for u in range(self.gen.num_upsample):
@@ -225,10 +252,10 @@ class GeneratorEngine:
             self.ps_bias[u] = b.view(-1, 4).t().contiguous().view(-1)
 
     def wf(self, i):
-        return self.flat_f.slices[i]
+        return _PackedW(self.flat_f.slices[i], self.fmt_f[i])
 
     def wb(self, i):
-        return self.flat_b.slices[i]
+        return _PackedW(self.flat_b.slices[i], self.fmt_b[i])
 
     # ------------------------------------------------------------------ building blocks
     def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float):

@@ -232,3 +232,92 @@ def test_bad_args_report_status(U):
     assert L.lib().srk_conv3x3(ctypes.byref(a), None) == -1
     with pytest.raises(RuntimeError):
         L.check(-2, "x")
+
+
+# ---------------------------------------------------------------------------------------------- split-bf16 mode
+def _pack_fmt1(U, w_oihw, transpose=False, ps=False):
+    L = U.L
+    co, ci = w_oihw.shape[:2]
+    K, M = (co, ci) if transpose else (ci, co)
+    src = w_oihw.contiguous().cuda()
+    dst = torch.empty(L.packed_floats(K, M), dtype=torch.float32, device="cuda")
+    t = L.PackTable(src.device, fmt=1)
+    t.add(src, dst, M=M, k_off=0, k_len=K, K_total=K, transpose=transpose, ps=ps)
+    t.run()
+    torch.cuda.synchronize()
+    return dst, src
+
+
+BF_TOL = 1e-4     # bf16x3: ~2^-16 relative operand precision -> a few 1e-5 of the output scale
+
+
+@pytest.mark.parametrize("ci,co,h,w,n", [(16, 64, 8, 32, 1), (64, 64, 64, 64, 2), (320, 64, 16, 40, 1), (64, 256, 9, 33, 1),
+                                         (128, 16, 20, 13, 2), (32, 96, 8, 8, 1)])
+def test_conv_bf16x3_fwd(U, ci, co, h, w, n):
+    L = U.L
+    x = _rand((n, ci, h, w), 41)
+    wt = _rand((co, ci, 3, 3), 42, 1.0 / np.sqrt(9 * ci))
+    b = _rand((co,), 43, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b), 0.01)
+    wp, _ = _pack_fmt1(U, wt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(x)), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01, wp_format=1)
+    err = U.rel_err(U.nchw(y), ref)
+    assert err < BF_TOL, err
+
+
+def test_conv_bf16x3_slices_residual_mask_and_dgrad(U):
+    L = U.L
+    n, h, w, F_ = 2, 12, 40, 16
+    xfull = _rand((n, 5 * F_, h, w), 44)
+    wt = _rand((F_, 3 * F_, 3, 3), 45, 0.05)
+    b = _rand((F_,), 46, 0.1)
+    r1 = _rand((n, F_, h, w), 47)
+    m = _rand((n, F_, h, w), 48)
+    ref = 0.2 * O.conv3x3(xfull[:, F_:4 * F_], wt, b) + 0.5 * r1
+    ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
+    buf = U.nhwc(xfull)
+    out = torch.zeros(n, h, w, 2 * F_, device="cuda")
+    wp, _ = _pack_fmt1(U, wt)
+    L.conv3x3(L.View(buf, F_, 3 * F_), wp, b.cuda(), L.View(out, F_, F_), N=n, H=h, W=w, OH=h, OW=w, Cin=3 * F_, Cout=F_,
+              alpha=0.2, r1=L.View(U.nhwc(r1)), beta1=0.5, mask=L.View(U.nhwc(m)), mask_slope=0.01, wp_format=1)
+    assert U.rel_err(U.nchw(out, F_, F_), ref) < BF_TOL
+    # data gradient through the transposed packing
+    x = _rand((n, 32, h, w), 49).requires_grad_(True)
+    w2 = _rand((48, 32, 3, 3), 50, 0.06)
+    y = O.conv3x3(x, w2, None)
+    dy = _rand(y.shape, 51)
+    y.backward(dy)
+    wpb, _ = _pack_fmt1(U, w2, transpose=True)
+    dx = torch.full((n, h, w, 32), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(dy)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=48, Cout=32, wp_format=1)
+    assert U.rel_err(U.nchw(dx), x.grad) < BF_TOL
+
+
+def test_conv_bf16x3_pixel_shuffle_and_unshuffle(U):
+    L = U.L
+    n, F_, h, w = 1, 64, 8, 12
+    x = _rand((n, F_, h, w), 52).requires_grad_(True)
+    wt = _rand((4 * F_, F_, 3, 3), 53, 0.04)
+    b = _rand((4 * F_,), 54, 0.1)
+    ref = O.pixel_shuffle(O.lrelu(O.conv3x3(x, wt, b), 0.01), 2)
+    wp, _ = _pack_fmt1(U, wt, ps=True)
+    bp = b.view(F_, 4).t().contiguous().view(-1).cuda()
+    y = torch.full((n, 2 * h, 2 * w, F_), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(x.detach())), wp, bp, L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, ps_out=True, slope=0.01, wp_format=1)
+    assert U.rel_err(U.nchw(y), ref.detach()) < BF_TOL
+    lin = O.pixel_shuffle(O.conv3x3(x, wt, None), 2)
+    g = _rand(lin.shape, 55)
+    lin.backward(g)
+    wpb, _ = _pack_fmt1(U, wt, transpose=True, ps=True)
+    dx = torch.full((n, h, w, F_), float("nan"), device="cuda")
+    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=4 * F_, Cout=F_, in_mode=L.IN_UNSHUFFLE, wp_format=1)
+    assert U.rel_err(U.nchw(dx), x.grad) < BF_TOL
+
+
+def test_conv_bf16x3_rejects_unsupported(U):
+    L = U.L
+    x = torch.zeros(1, 8, 8, 8, device="cuda"); y = torch.zeros(1, 8, 8, 64, device="cuda")
+    wp = torch.zeros(L.packed_floats(8, 64), device="cuda")
+    with pytest.raises(RuntimeError):
+        L.conv3x3(L.View(x), wp, None, L.View(y), N=1, H=8, W=8, OH=8, OW=8, Cin=8, Cout=64, wp_format=1)   # Cin % 16 != 0
