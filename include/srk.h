@@ -105,6 +105,8 @@ typedef struct srk_wgrad_args {
   float scale;
   int32_t accumulate;
   void* workspace; size_t workspace_bytes;
+  int32_t precision;        /* 0: exact fp32 MFMA (default).  1: split-bf16 operands, 3 bf16 MFMAs per product, fp32
+                               accumulate (opt-in; stride 1, Cin % 8 == 0, Cout % 8 == 0, 16-byte addressable views) */
 } srk_wgrad_args;
 
 int srk_conv3x3_wgrad(const srk_wgrad_args* a, void* stream);

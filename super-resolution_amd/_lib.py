@@ -47,7 +47,7 @@ class WgradArgs(C.Structure):
         ("x", _fp), ("x_ldc", C.c_int32), ("x_coff", C.c_int32), ("in_slope", C.c_float),
         ("dy", _fp), ("dy_ldc", C.c_int32), ("dy_coff", C.c_int32),
         ("dw", _fp), ("db", _fp), ("scale", C.c_float), ("accumulate", C.c_int32),
-        ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+        ("workspace", _fp), ("workspace_bytes", C.c_size_t), ("precision", C.c_int32),
     ]
 
 
@@ -207,9 +207,10 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
-                  scale=1.0, accumulate=False, in_slope=1.0):
+                  scale=1.0, accumulate=False, in_slope=1.0, precision=0):
     a = WgradArgs()
     a.in_slope = in_slope
+    a.precision = precision
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout, a.stride, a.dy_mode = N, H, W, OH, OW, Cin, Cout, stride, dy_mode
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
     a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff
@@ -227,7 +228,7 @@ def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, C
     check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
 
 
-def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLAIN):
+def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLAIN, precision=0):
     """problems: list of dicts(x=View, dy=View, dw=Tensor, db=Tensor|None, Cin, Cout, scale, accumulate, in_slope)."""
     n = len(problems)
     arr = (WgradArgs * n)()
@@ -240,13 +241,14 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
         a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff
         a.dw, a.db = p["dw"].data_ptr(), ptr(p.get("db"))
         a.scale, a.accumulate = p.get("scale", 1.0), int(p.get("accumulate", False))
+        a.precision = precision
         flops += 2.0 * N * OH * OW * a.Cout * a.Cin * 9
     nbytes = C.c_size_t(0)
     check(lib().srk_conv3x3_wgrad_batched_workspace(arr, n, C.byref(nbytes)), "srk_conv3x3_wgrad_batched_workspace")
     ws = _workspace(nbytes.value, problems[0]["x"].t.device)
     arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket(f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce", flops)
+        e0, e1 = KernelTimer.bracket((f"wgrad_bf16x3_kernel<{dy_mode}>+reduce" if precision == 1 else f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce"), flops)
         e0.record()
         check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
         e1.record()

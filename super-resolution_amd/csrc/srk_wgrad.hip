@@ -213,6 +213,208 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") weight gradient, opt-in (srk_wgrad_args.precision = 1), stride 1.
+// Same decomposition as above (workgroup = one 64x64x9 chunk, wave (a,b) = nine 32x32 tiles, K = pixels) on
+// v_mfma_f32_32x32x16_bf16 with operands split x = hi + lo:  dy*x ~= dy_hi*x_hi + dy_hi*x_lo + dy_lo*x_hi (fp32
+// accumulate).  K is the PIXEL index, so each lane needs 8 consecutive pixels of one channel: the tiles stay
+// [pixel][32 ch] in LDS (64-byte rows, four consecutive rows hit disjoint banks) and are read with the hardware
+// transpose ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group).  7 waves: 0-3 MFMA, 4-6 stage the next
+// pixel tile (global fp32 -> split -> LDS) into the other LDS buffer.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BW_NLOAD = 3;
+constexpr int BW_THREADS = 64 * (4 + BW_NLOAD);
+constexpr int BW_TH = 4, BW_TP = BW_TH * WTW, BW_IW = WTW + 2, BW_NHP = (BW_TH + 2) * BW_IW;     // 64 px, 108 halo px
+constexpr int BW_DY_BYTES = 2 * 2 * BW_TP * 64;          // [part][half][64 px][32 ch bf16]
+constexpr int BW_X_BYTES = 2 * 2 * BW_NHP * 64;          // [part][half][108 px][32 ch bf16]
+constexpr int BW_BUF_BYTES = BW_DY_BYTES + BW_X_BYTES;   // 44,032 B
+
+__device__ __forceinline__ wbf16x4 tr_read(const char* p) {
+  return __builtin_bit_cast(wbf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)p));
+}
+
+template <int DYMODE>
+__global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B, float* part, float* pbias) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BW_BUF_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int p = blockIdx.x, chunk = blockIdx.y;
+  const WProb& a = B.prob[B.c_prob[chunk]];
+  const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
+  const int cin0 = cy * 64, cout0 = cz * 64;
+  const int Cps = a.Cout >> 2;
+  const int t_begin = p * B.tpb;
+  int t_end = t_begin + B.tpb;
+  if (t_end > B.total_tiles) t_end = B.total_tiles;
+
+  if (wv >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wv - 4;
+    const float in_slope = a.in_slope;
+    constexpr int NSL = BW_TP * 8 + BW_NHP * 8;                    // 8-channel slots per tile: 512 (dy) + 864 (x)
+    constexpr int NIT = (NSL + 64 * BW_NLOAD - 1) / (64 * BW_NLOAD);
+    auto stage = [&](int tile, int b) {
+      int tt = tile;
+      const int tx = tt % B.tilesW; tt /= B.tilesW;
+      const int ty = tt % B.tilesH; tt /= B.tilesH;
+      const int n = tt;
+      const int oh0 = ty * BW_TH, ow0 = tx * WTW;
+      char* buf = smem + b * BW_BUF_BYTES;
+      float4 ra[NIT], rb[NIT];
+      int dst[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int slot = lane + 64 * (lw + BW_NLOAD * i);
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        int d = -1;
+        if (slot < BW_TP * 8) {
+          const int px = slot >> 3, c8 = slot & 7;
+          const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
+          const int co = cout0 + 8 * c8;
+          d = ((c8 >> 2) * BW_TP + px) * 64 + (c8 & 3) * 16;               // hi plane; lo = + 2*BW_TP*64
+          if (oh < B.OH && ow < B.OW && co < a.Cout) {
+            const float* src;
+            if (DYMODE == SRK_IN_UNSHUFFLE) {
+              const int ij = co / Cps, c = co - ij * Cps;
+              src = a.dy + ((long)(n * 2 * B.OH + 2 * oh + (ij >> 1)) * (2 * B.OW) + 2 * ow + (ij & 1)) * a.dy_ldc + a.dy_coff + c;
+            } else {
+              src = a.dy + ((long)(n * B.OH + oh) * B.OW + ow) * a.dy_ldc + a.dy_coff + co;
+            }
+            va = *reinterpret_cast<const float4*>(src);
+            vb = *reinterpret_cast<const float4*>(src + 4);
+          }
+        } else if (slot < NSL) {
+          const int s2 = slot - BW_TP * 8;
+          const int hp = s2 >> 3, c8 = s2 & 7;
+          const int hy = hp / BW_IW, hx = hp - hy * BW_IW;
+          const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+          const int ci = cin0 + 8 * c8;
+          d = BW_DY_BYTES + ((c8 >> 2) * BW_NHP + hp) * 64 + (c8 & 3) * 16;   // hi plane; lo = + 2*BW_NHP*64
+          if (ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
+            const float* src = a.x + ((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff + ci;
+            va = *reinterpret_cast<const float4*>(src);
+            vb = *reinterpret_cast<const float4*>(src + 4);
+            if (in_slope != 1.f) {
+              va.x = va.x > 0.f ? va.x : va.x * in_slope; va.y = va.y > 0.f ? va.y : va.y * in_slope;
+              va.z = va.z > 0.f ? va.z : va.z * in_slope; va.w = va.w > 0.f ? va.w : va.w * in_slope;
+              vb.x = vb.x > 0.f ? vb.x : vb.x * in_slope; vb.y = vb.y > 0.f ? vb.y : vb.y * in_slope;
+              vb.z = vb.z > 0.f ? vb.z : vb.z * in_slope; vb.w = vb.w > 0.f ? vb.w : vb.w * in_slope;
+            }
+          }
+        }
+        ra[i] = va; rb[i] = vb; dst[i] = d;
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if (dst[i] < 0) continue;
+        wf32x8 v;
+        v[0] = ra[i].x; v[1] = ra[i].y; v[2] = ra[i].z; v[3] = ra[i].w; v[4] = rb[i].x; v[5] = rb[i].y; v[6] = rb[i].z; v[7] = rb[i].w;
+        const wbf16x8 hi = __builtin_convertvector(v, wbf16x8);
+        const wf32x8 hf = __builtin_convertvector(hi, wf32x8);
+        const wbf16x8 lo = __builtin_convertvector(v - hf, wbf16x8);
+        const int lo_off = dst[i] < BW_DY_BYTES ? 2 * BW_TP * 64 : 2 * BW_NHP * 64;
+        *reinterpret_cast<float4*>(buf + dst[i]) = __builtin_bit_cast(float4, hi);
+        *reinterpret_cast<float4*>(buf + dst[i] + lo_off) = __builtin_bit_cast(float4, lo);
+      }
+    };
+    if (t_begin < t_end) stage(t_begin, 0);
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      if (tile + 1 < t_end) stage(tile + 1, ((tile - t_begin) & 1) ^ 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- MFMA waves
+  const int wa = wv & 1, wb = wv >> 1;
+  const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
+  const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  wbf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+  // transposed-read addressing: 16-lane group g = lane>>4 reads 4 pixel rows x 16 channels; lane 4q+pp of the group
+  // supplies row q, channels 4pp..4pp+3; it RECEIVES channel (lane & 15) of the group's 16, i.e. channel lane&31.
+  const int g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lane_col = (16 * (g & 1) + 4 * pp) * 2;                     // byte offset inside a 64-byte pixel row
+  // A (dy): pixel of k-step kk, read rd: 16kk + 8h + 4rd + q
+  const int a_lane = (wa * BW_TP + 8 * h + q) * 64 + lane_col;          // + (16kk + 4rd)*64, + 2*BW_TP*64 for lo
+  // B (x halo): pixel (kk + r)*IW + 8h + 4rd + q + s
+  const int b_lane = BW_DY_BYTES + (wb * BW_NHP + 8 * h + q) * 64 + lane_col;   // + ((kk+r)*IW + 4rd + s)*64, + 2*BW_NHP*64 for lo
+  constexpr int A_LO = 2 * BW_TP * 64, B_LO = 2 * BW_NHP * 64;
+
+  __syncthreads();                               // first tile staged
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const char* buf = smem + ((tile - t_begin) & 1) * BW_BUF_BYTES;
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < BW_TH; ++kk) {
+        wbf16x8 ah, al;
+        {
+          const wbf16x4 h0 = tr_read(buf + a_lane + (16 * kk) * 64), h1 = tr_read(buf + a_lane + (16 * kk + 4) * 64);
+          const wbf16x4 l0 = tr_read(buf + a_lane + A_LO + (16 * kk) * 64), l1 = tr_read(buf + a_lane + A_LO + (16 * kk + 4) * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ah[j] = h0[j]; ah[4 + j] = h1[j]; al[j] = l0[j]; al[4 + j] = l1[j]; }
+        }
+        if (do_bias) {
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+        }
+        wbf16x8 bh[2], bl[2];
+        auto ld_b = [&](int pbuf, int tap) {
+          const int r = tap / 3, s = tap - 3 * r;
+          const char* base = buf + b_lane + ((kk + r) * BW_IW + s) * 64;
+          const wbf16x4 h0 = tr_read(base), h1 = tr_read(base + 4 * 64);
+          const wbf16x4 l0 = tr_read(base + B_LO), l1 = tr_read(base + B_LO + 4 * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bh[pbuf][j] = h0[j]; bh[pbuf][4 + j] = h1[j]; bl[pbuf][j] = l0[j]; bl[pbuf][4 + j] = l1[j]; }
+        };
+        ld_b(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int cur = tap & 1;
+          if (tap < 8) ld_b(cur ^ 1, tap + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cur], acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cur], acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cur], acc[tap], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int hl = lane >> 5, l32 = lane & 31;
+  if (active) {
+    float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+        dst[(tap * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = acc[tap][reg];
+      }
+  }
+  if (do_bias && l32 == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+      pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + i] = accb[reg];
+    }
+  }
+}
+
 // grid (64 local cout rows, n_chunks), 576 threads = (tap, 64 cin).  Sums the P partials in fixed order,
 // transposes [tap][c] -> [c][tap] through LDS and writes one contiguous OIHW row segment dW[o][c0..c0+63][0..8].
 __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias) {
@@ -422,6 +624,23 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
   }
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
+  if (a0.precision == 1) {
+    // split-bf16: stride 1, 8-channel slots
+    bool ok = vec && a0.stride == 1;
+    for (int i = 0; i < n; ++i) {
+      ok = ok && args[i].precision == 1 && (args[i].Cin % 8 == 0) && (args[i].Cout % 8 == 0);
+      if (a0.dy_mode == SRK_IN_UNSHUFFLE) ok = ok && ((args[i].Cout >> 2) % 8 == 0);
+    }
+    if (!ok) return SRK_ERR_UNSUPPORTED;
+    dim3 grid(B.P, B.n_chunks);
+    if (a0.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_UNSHUFFLE>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+    SRK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
+    SRK_CHECK_LAUNCH();
+    return SRK_OK;
+  }
+  if (a0.precision != 0) return SRK_ERR_UNSUPPORTED;
   if (a0.dy_mode == SRK_IN_UNSHUFFLE) {
     if (!vec) return SRK_ERR_ALIGNMENT;
     return launch<1, SRK_IN_UNSHUFFLE, true>(B, part, pbias, st);

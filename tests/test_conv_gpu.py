@@ -321,3 +321,51 @@ def test_conv_bf16x3_rejects_unsupported(U):
     wp = torch.zeros(L.packed_floats(8, 64), device="cuda")
     with pytest.raises(RuntimeError):
         L.conv3x3(L.View(x), wp, None, L.View(y), N=1, H=8, W=8, OH=8, OW=8, Cin=8, Cout=64, wp_format=1)   # Cin % 16 != 0
+
+
+@pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 16, 16, 2), (128, 64, 12, 20, 3), (320, 64, 64, 64, 1), (16, 16, 9, 33, 2), (64, 8, 8, 8, 1)])
+def test_conv_wgrad_bf16x3(U, ci, co, h, w, n):
+    """split-bf16 weight gradient (transposed LDS reads, 3 MFMAs per product)."""
+    L = U.L
+    x = _rand((n, ci, h, w), 61)
+    wt = _rand((co, ci, 3, 3), 62, 0.05).requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    y = O.conv3x3(x, wt, b)
+    dy = _rand(y.shape, 63)
+    y.backward(dy)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+    db = torch.full((co,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, precision=1)
+    assert U.rel_err(dw.cpu(), wt.grad) < BF_TOL
+    assert U.rel_err(db.cpu(), b.grad) < BF_TOL
+
+
+def test_conv_wgrad_bf16x3_batched_and_unshuffle(U):
+    L = U.L
+    n, F_, h, w = 2, 16, 8, 24
+    buf = _rand((n, 5 * F_, h, w), 64)
+    E = _rand((n, 5 * F_, h, w), 65)
+    bufd, Ed = U.nhwc(buf), U.nhwc(E)
+    probs, refs = [], []
+    for k in (1, 3, 5):
+        wt = torch.zeros(F_, k * F_, 3, 3, requires_grad=True); bb = torch.zeros(F_, requires_grad=True)
+        y = O.conv3x3(buf[:, :k * F_], wt, bb)
+        y.backward(E[:, (5 - k) * F_:(6 - k) * F_])
+        dw = torch.full((F_, k * F_, 3, 3), float("nan"), device="cuda"); db = torch.full((F_,), float("nan"), device="cuda")
+        probs.append(dict(x=L.View(bufd, 0, k * F_), dy=L.View(Ed, (5 - k) * F_, F_), dw=dw, db=db, Cin=k * F_, Cout=F_, scale=0.5))
+        refs.append((wt.grad, bb.grad))
+    L.conv3x3_wgrad_batched(probs, N=n, H=h, W=w, OH=h, OW=w, precision=1)
+    for pr, (gw, gb) in zip(probs, refs):
+        assert U.rel_err(pr["dw"].cpu(), 0.5 * gw) < BF_TOL and U.rel_err(pr["db"].cpu(), 0.5 * gb) < BF_TOL
+    # PixelShuffle-side dy
+    F2 = 32
+    x = _rand((1, F2, 8, 12), 66)
+    wt = _rand((4 * F2, F2, 3, 3), 67, 0.05).requires_grad_(True)
+    b = torch.zeros(4 * F2, requires_grad=True)
+    y = O.pixel_shuffle(O.conv3x3(x, wt, b), 2)
+    g = _rand(y.shape, 68)
+    y.backward(g)
+    dw = torch.full((4 * F2, F2, 3, 3), float("nan"), device="cuda"); db = torch.full((4 * F2,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(g)), dw, db, N=1, H=8, W=12, OH=8, OW=12, Cin=F2, Cout=4 * F2,
+                    dy_mode=L.IN_UNSHUFFLE, precision=1)
+    assert U.rel_err(dw.cpu(), wt.grad) < BF_TOL and U.rel_err(db.cpu(), b.grad) < BF_TOL

@@ -210,3 +210,27 @@ def test_reference_written_checkpoint_loads_and_matches(srk, golden_dir):
         y = gen(torch.from_numpy(d["x"]).cuda())
     ref = torch.from_numpy(d["y_eval"])
     assert (y.cpu() - ref).abs().max().item() < OUT_TOL * max(ref.abs().max().item(), 1e-3)
+
+
+@pytest.mark.parametrize("name", ["G4_gen_f16_r1_u2", "G5_config0"])
+def test_generator_golden_bf16x3_mode(srk, golden_dir, name):
+    """Opt-in split-bf16 precision (engine.precision = "bf16x3"): forward / data-gradient convs run as three bf16 MFMAs
+    per product.  Still inside BASELINE's 1e-3 on outputs; gradients within 5e-3 of each tensor's max-abs."""
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    c, f, r, u = [int(v) for v in d["cfg"]]
+    gen = srk.GeneratorRRDB(c, filters=f, num_res_blocks=r, num_upsample=u, res_scale=float(d["res_scale"])).cuda()
+    gen._engine.precision = "bf16x3"
+    _load_closed_form(gen, float(d["gain"]))
+    x = torch.from_numpy(d["x"]).cuda()
+    gen.train()
+    y = gen(x)
+    assert any(v == 1 for v in gen._engine.fmt_f.values()) and any(v == 1 for v in gen._engine.fmt_b.values())
+    err = rel(y.cpu(), torch.from_numpy(d["y_train"]))
+    assert err < OUT_TOL, err
+    loss = (y - torch.from_numpy(d["target"]).cuda()).abs().mean()
+    assert abs(loss.item() - float(d["loss"])) < 1e-4 * max(1.0, float(d["loss"]))
+    loss.backward()
+    for k, p in gen.named_parameters():
+        key = "grad." + k
+        if key in d.files:
+            assert rel(p.grad.cpu(), torch.from_numpy(d[key])) < 5e-3, k
