@@ -42,6 +42,9 @@ def parse():
                     help="gan = BASELINE.json's metric (full G+D iteration, configs[2]); g_only = warm-up iteration (configs[1])")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
     ap.add_argument("--res-blocks", type=int, default=23)
+    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", "f32"), choices=["f32", "bf16x3"],
+                    help="f32 (default, headline): exact-fp32 MFMA everywhere.  bf16x3: opt-in split-bf16 MFMA mode")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra opt-in bf16x3 measurement and the full-size parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket conv launches with events")
     return ap.parse_args()
@@ -98,6 +101,27 @@ def cpu_baseline(res_blocks, workload):
                       f"{dt*1e3:.0f} ms/iter, torch CPU fp32"}
 
 
+def full_size_parity(sr, res_blocks, dev):
+    """Generator forward at BASELINE's full architecture (F=64, R=23, 4x) on 2 jet images, HIP path vs the CPU oracle
+    on identical weights/inputs: max |diff| / max |ref| for the exact-fp32 mode and for the opt-in bf16x3 mode."""
+    from oracle import esrgan_oracle as O
+    sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
+    lr, hr = O.jet_images(2, 1, HR, HR, 4321, FACTOR)
+    with torch.no_grad():
+        ref, _ = O.generator_forward(sd, lr, res_blocks, 2, 0.2, training=True)
+    gen = sr.GeneratorRRDB(1, filters=64, num_res_blocks=res_blocks, num_upsample=2).to(dev)
+    gen.load_state_dict(sd)
+    out = {}
+    for mode in ("f32", "bf16x3"):
+        gen._engine.precision = mode
+        with torch.no_grad():
+            y = gen(lr.to(dev)).cpu()
+        out[mode] = float((y - ref).abs().max() / ref.abs().max())
+    out["tolerance"] = 1e-3
+    out["what"] = "GeneratorRRDB(1,64,%d,num_upsample=2) forward, 2x1x64x64 -> 2x1x256x256, max-abs relative error vs CPU oracle" % res_blocks
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -124,6 +148,7 @@ def main():
     torch.manual_seed(0)                                  # identical replicas on every rank
     stepper = train.Stepper(workload=args.workload, res_blocks=args.res_blocks, device=dev, hr=HR, factor=FACTOR,
                             distributed=(world > 1))
+    stepper.generator._engine.precision = args.precision
     lr_img, hr_img = synth_batch(batch, dev, 1234 + rank)
 
     def barrier():
@@ -147,6 +172,26 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+
+    # ---- extra, outside the headline: the opt-in split-bf16 mode on the same workload (every rank takes part)
+    alt = None
+    if not args.no_alt and args.precision == "f32":
+        stepper.generator._engine.precision = "bf16x3"
+        for _ in range(2):
+            stepper.step(lr_img, hr_img)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            stepper.step(lr_img, hr_img)
+        barrier()
+        adt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(adt, op=dist.ReduceOp.MAX)
+        adt = adt.item()
+        stepper.generator._engine.precision = "f32"
+        alt = {"precision": "bf16x3: fwd/dgrad/wgrad convs as 3 bf16 MFMAs per product (operands split hi+lo, fp32 accumulate); "
+                            "opt-in, NOT the headline", "value": world * batch * HR * HR * args.steps / adt, "unit": "HR-px/s",
+               "ms_per_step": adt / args.steps * 1e3}
     ms = dt / args.steps * 1e3
     value = world * batch * HR * HR * args.steps / dt
 
@@ -172,18 +217,21 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args.res_blocks, args.workload)
+        parity = None
+        if not args.no_alt and world == 1:
+            parity = full_size_parity(sr, args.res_blocks, dev)
         out = {
             "metric": "HR-pixels/s + ms/iter (G+D step), 64->256 jet images" if args.workload == "gan"
                       else "HR-pixels/s + ms/iter (G-only warm-up step), 64->256 jet images",
             "value": value, "unit": "HR-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 MFMA operands, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: GeneratorRRDB(1,64,{args.res_blocks},num_upsample=2) 64x64->256x256, "
                                    f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
                                                            if args.workload == "gan" else ", L1 + Adam"),
                        "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
                        "generator_train_gflop_per_image": 971.4},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "split_bf16_mode": alt, "full_size_parity": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
