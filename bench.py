@@ -139,20 +139,22 @@ def main():
     L = sr._lib
 
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SRK_FORCE_DIST", "0") == "1"      # rehearse the N>1 code path with a 1-rank RCCL group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     batch = args.batch or (16 if args.workload == "g_only" else 32)
     torch.manual_seed(0)                                  # identical replicas on every rank
     stepper = train.Stepper(workload=args.workload, res_blocks=args.res_blocks, device=dev, hr=HR, factor=FACTOR,
-                            distributed=(world > 1))
+                            distributed=(world > 1 or force_dist))
     stepper.generator._engine.precision = args.precision
     lr_img, hr_img = synth_batch(batch, dev, 1234 + rank)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +236,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "split_bf16_mode": alt, "full_size_parity": parity,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
