@@ -161,11 +161,17 @@ def main():
     for _ in range(args.warmup):
         stepper.step(lr_img, hr_img)
     barrier()
-    if not args.no_kernel_timing:
-        L.KernelTimer.start()
+    # Per-launch HIP events bracket every conv / wgrad launch during the FIRST timed step only: bracketing all of them
+    # costs ~4.5 % of the step (measured 132.4 vs 126.5 ms), one step in K keeps the perturbation of `value` below
+    # 0.5 % while still timing >1000 launches live inside the timed region.
+    timed_probe = 0 if args.no_kernel_timing else 1
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        if it < timed_probe and it == 0:
+            L.KernelTimer.start()
         stepper.step(lr_img, hr_img)
+        if it + 1 == timed_probe:
+            L.KernelTimer.active = False           # stop recording; elapsed times are read after the region
     barrier()
     dt = time.perf_counter() - t0
     ktimes = None if args.no_kernel_timing else L.KernelTimer.stop()
@@ -215,7 +221,8 @@ def main():
                     "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
                     "avg_gflop_per_launch": round(st["flops"] / st["n"] / 1e9, 3),
-                    "conv_time_share": round(sum(v["ms"] for v in ktimes.values()) / (dt * 1e3), 4)}
+                    "probe": "events around every conv/wgrad launch of the first timed step",
+                    "conv_time_share_of_probed_step": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args.res_blocks, args.workload)

@@ -78,6 +78,8 @@ class GeneratorEngine:
         # "f32": exact-fp32 MFMA everywhere (default).  "bf16x3": forward / data-gradient convs whose K is a multiple
         # of 16 run as 3 split-bf16 MFMAs per product (fp32 accumulate, ~2^-16 operand precision); opt-in.
         self.precision = os.environ.get("SRK_PRECISION", "f32")
+        self.use_graphs = os.environ.get("SRK_GRAPHS", "0") == "1"     # hipGraph replay of forward / backward (_GraphSet)
+        self._graphs = {}
         self._side = None            # second HIP stream: weight-gradient kernels overlap the data-gradient chain
         self.overlap_wgrad = os.environ.get("SRK_OVERLAP_WGRAD", "0") != "0"   # measured +1.2 % only; off keeps per-kernel timing clean
 
@@ -538,16 +540,78 @@ class GeneratorEngine:
         return dx, grads
 
 
+class _GraphSet:
+    """hipGraph capture of the generator's forward and backward launch sequences for one (shape, mode).
+
+    engine.forward / engine.backward are pure launch sequences on the current stream (no host sync, every buffer from
+    the torch allocator), i.e. ~1050 + ~1500 kernel nodes per iteration whose Python/ctypes launch cost (~10 us each)
+    is the gap between kernels.  Captured once (after the usual side-stream warm-up), replayed with static input /
+    output / activation / gradient buffers; weight packing is inside the graphs, so optimizer updates are picked up."""
+
+    def __init__(self, engine, x, need_grad, x_req):
+        self.engine = engine
+        dev = x.device
+        self.x_static = x.detach().clone()
+        self.need_grad, self.x_req = need_grad, x_req
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):                       # warm-up: builds pack tables, workspaces, allocator pools
+            for _ in range(2):
+                out, saved = engine.forward(self.x_static, need_grad)
+                if need_grad:
+                    engine.backward(saved, torch.zeros_like(out), x_req)
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            self.out_static, self.saved = engine.forward(self.x_static, need_grad)
+        self.g_bwd = None
+        if need_grad:
+            self.gout_static = torch.zeros_like(self.out_static)
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+                self.dx_static, self.grads = engine.backward(self.saved, self.gout_static, x_req)
+        torch.cuda.synchronize()
+
+    def forward(self, x):
+        self.x_static.copy_(x)
+        self.g_fwd.replay()
+        return self.out_static
+
+    def backward(self, g_out):
+        self.gout_static.copy_(g_out)
+        self.g_bwd.replay()
+        return self.dx_static, self.grads
+
+
+def _graphs_enabled(engine):
+    """Graph replay is used when asked for (SRK_GRAPHS=1 / engine.use_graphs) and nothing needs eager launches:
+    no per-launch kernel timing, no in-backward RCCL exchange, no side stream."""
+    return engine.use_graphs and not L.KernelTimer.active and not engine._sync and not engine.overlap_wgrad
+
+
 class _GeneratorFn(torch.autograd.Function):
     """raw = conv3(upsample(conv1(x) + conv2(RRDB^R(conv1(x))))) as one autograd node."""
 
     @staticmethod
     def forward(ctx, engine: GeneratorEngine, x, *params):
         need = any(ctx.needs_input_grad)
-        out, saved = engine.forward(x.detach(), need_grad=need)
         ctx.engine = engine
-        ctx.saved = saved
         ctx.x_req = x.requires_grad
+        ctx.graph = None
+        if _graphs_enabled(engine) and x.is_cuda:
+            key = (tuple(x.shape), need, x.requires_grad, engine.precision, tuple(p.data_ptr() for p in params))
+            gs = engine._graphs.get(key)
+            if gs is None:
+                if len(engine._graphs) >= 4:
+                    engine._graphs.clear()
+                gs = engine._graphs[key] = _GraphSet(engine, x.detach().contiguous().float(), need, x.requires_grad)
+            ctx.graph = gs
+            ctx.saved = True if need else None
+            return gs.forward(x.detach())
+        out, saved = engine.forward(x.detach(), need_grad=need)
+        ctx.saved = saved
         return out
 
     @staticmethod
@@ -555,7 +619,10 @@ class _GeneratorFn(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("generator backward called but forward ran without grad")
         eng = ctx.engine
-        dx, grads = eng.backward(ctx.saved, g_out, ctx.x_req)
+        if ctx.graph is not None:
+            dx, grads = ctx.graph.backward(g_out)
+        else:
+            dx, grads = eng.backward(ctx.saved, g_out, ctx.x_req)
         ctx.saved = None
         return (None, dx) + tuple(grads[p] for p in eng.params())
 
