@@ -27,7 +27,7 @@ constexpr int BNHP = BIH * BIW;                  // 340 halo pixels
 constexpr int XP4 = 4 * BNHP;                    // float4-sized (16 B) units of the x planes per buffer
 constexpr int WP4 = 9 * 2 * 2 * 64;              // 16-B units of the weights per buffer (2304)
 constexpr int BBUF4 = XP4 + WP4;                 // 3664 units = 58,624 B
-constexpr int NLOAD = 3;                         // loader waves
+constexpr int NLOAD = 3;                         // loader waves (4 measured identical: the main loop is not loader-bound)
 constexpr int BTHREADS = 64 * (4 + NLOAD);
 
 template <int MODE>

@@ -19,6 +19,7 @@
 // Mirrors the autograd weight/bias gradient of nn.Conv2d at /root/reference/models.py:19,63,67,87,97,99,
 // 142,144,168.
 #include "srk_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
 // wave shuffle reduction, an LDS reduction over the 4 waves and a fixed-order second pass over the workgroups.
 constexpr int C1_CG = 16;                 // output channels per grid.y slice
 constexpr int C1_VALS = C1_CG * 10;       // 9 taps + bias per channel
-constexpr int C1_BLOCKS = 512;
+constexpr int C1_BLOCKS = 256;
 
 template <int S>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* part) {
@@ -513,14 +514,17 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* pa
     part[((long)blockIdx.x * gridDim.y + cg) * C1_VALS + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
+// one wave per output value: lanes stride over the workgroup partials, fixed shuffle tree (deterministic)
 __global__ void wgrad_c1_reduce_kernel(const WBatch B, const float* __restrict__ part, int nblocks, int ngroups) {
   const WProb& a = B.prob[0];
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= ngroups * C1_VALS) return;
-  const int cg = gid / C1_VALS, r = gid % C1_VALS, o = cg * C1_CG + r / 10, t = r % 10;
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int cg = v / C1_VALS, r = v % C1_VALS, o = cg * C1_CG + r / 10, t = r % 10;
   if (o >= a.Cout) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[((long)b * ngroups + cg) * C1_VALS + r];
+  for (int b = lane; b < nblocks; b += 64) s += part[((long)b * ngroups + cg) * C1_VALS + r];
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
+  if (lane != 0) return;
   s *= a.scale;
   if (t < 9) { float* d = a.dw + o * 9 + t; *d = a.accumulate ? *d + s : s; }
   else if (a.db) { float* d = a.db + o; *d = a.accumulate ? *d + s : s; }
@@ -556,7 +560,11 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   B.tilesW = srk_div_up(a0.OW, WTW);
   B.tilesH = srk_div_up(a0.OH, TH);
   B.total_tiles = a0.N * B.tilesH * B.tilesW;
-  int target = 512 / nc;
+  // ~2 workgroups per CU.  (A/B on one box, full GAN iteration: 512 -> 273.1 ms, 256 -> 276.7 ms for the 1-2 chunk
+  // problems: the second workgroup per CU hides more than the extra partial-sum traffic costs.)
+  static int small_target = -1;
+  if (small_target < 0) { const char* e = getenv("SRK_WGRAD_SMALL_TARGET"); small_target = e ? atoi(e) : 512; }
+  int target = (nc <= 2 ? small_target : 512) / nc;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
   // split finer than 8 tiles per workgroup
@@ -618,7 +626,7 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
     if (a0.stride == 1) hipLaunchKernelGGL(wgrad_c1_kernel<1>, dim3(nblocks, ngroups), dim3(256), 0, st, B, part);
     else hipLaunchKernelGGL(wgrad_c1_kernel<2>, dim3(nblocks, ngroups), dim3(256), 0, st, B, part);
     SRK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((ngroups * C1_VALS + 255) / 256), dim3(256), 0, st, B, (const float*)part, nblocks, ngroups);
+    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3(ngroups * C1_VALS), dim3(64), 0, st, B, (const float*)part, nblocks, ngroups);
     SRK_CHECK_LAUNCH();
     return SRK_OK;
   }
