@@ -1,0 +1,127 @@
+"""GPU: size-independent properties at BASELINE.json's FULL sizes (F=64, 64x64 LR, batch 16, Cin up to 320, R=23), where
+the CPU oracle is too slow to be the checker for every case:
+  * adjointness  <conv(x), y> == <x, conv^T(y)>  and  <dW, V> == <dy, conv_V(x)>  (data-/weight-gradient kernels vs the
+    forward kernel, no oracle needed),
+  * linearity of the un-activated convolution,
+  * batch independence of the generator (image i does not depend on the other images; bit-exact),
+  * run-to-run determinism of forward + backward (all 702 gradient tensors bit-identical),
+  * plus one direct oracle comparison of the full-depth generator on 2 images (a few seconds of CPU).
+Both the exact-fp32 kernels and the opt-in split-bf16 kernels are exercised.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import esrgan_oracle as O  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+N, H, W, F = 16, 64, 64, 64
+
+
+@pytest.fixture(scope="module")
+def U():
+    import srk_testutil
+    return srk_testutil
+
+
+def _dot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+def _pack(L, w, fmt, transpose=False):
+    co, ci = w.shape[:2]
+    K, M = (co, ci) if transpose else (ci, co)
+    dst = torch.empty(L.packed_floats(K, M), dtype=torch.float32, device="cuda")
+    t = L.PackTable(w.device, fmt=fmt)
+    t.add(w, dst, M=M, k_off=0, k_len=K, K_total=K, transpose=transpose)
+    t.run()
+    return dst
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("ci", [64, 320])
+def test_adjoint_and_linearity_at_full_dense_block_size(U, fmt, ci):
+    L = U.L
+    g = torch.Generator(device="cuda").manual_seed(ci + fmt)
+    x = torch.randn(N, H, W, 5 * F, device="cuda", generator=g)
+    x2 = torch.randn(N, H, W, 5 * F, device="cuda", generator=g)
+    y = torch.randn(N, H, W, F, device="cuda", generator=g)
+    w = torch.randn(F, ci, 3, 3, device="cuda", generator=g) * 0.02
+    wp, wpt = _pack(L, w, fmt), _pack(L, w, fmt, transpose=True)
+    geo = dict(N=N, H=H, W=W, OH=H, OW=W)
+
+    def conv(inp):
+        out = torch.empty(N, H, W, F, device="cuda")
+        L.conv3x3(L.View(inp, 0, ci), wp, None, L.View(out), Cin=ci, Cout=F, wp_format=fmt, **geo)
+        return out
+    cx = conv(x)
+    # <conv(x), y> == <x, dgrad(y)>
+    dx = torch.empty(N, H, W, ci, device="cuda")
+    L.conv3x3(L.View(y), wpt, None, L.View(dx), Cin=F, Cout=ci, wp_format=fmt, **geo)
+    lhs, rhs = _dot(cx, y), _dot(x[..., :ci], dx)
+    tol = 2e-5 if fmt == 0 else 2e-4
+    assert abs(lhs - rhs) <= tol * max(abs(lhs), abs(rhs), (cx.double().norm() * y.double().norm()).item() * 1e-2), (lhs, rhs)
+    # linearity: conv(2x - 3x2) == 2conv(x) - 3conv(x2)
+    lin = conv(2 * x - 3 * x2)
+    ref = 2 * cx - 3 * conv(x2)
+    assert ((lin - ref).abs().max() / ref.abs().max()).item() < (1e-5 if fmt == 0 else 1e-4)
+    # <dW, V> == <y, conv_V(x)>  (weight gradient vs forward with weights V)
+    dw = torch.empty(F, ci, 3, 3, device="cuda"); db = torch.empty(F, device="cuda")
+    L.conv3x3_wgrad(L.View(x, 0, ci), L.View(y), dw, db, Cin=ci, Cout=F, precision=fmt, **geo)
+    V = torch.randn(F, ci, 3, 3, device="cuda", generator=g) * 0.02
+    cv = torch.empty(N, H, W, F, device="cuda")
+    L.conv3x3(L.View(x, 0, ci), _pack(L, V, fmt), None, L.View(cv), Cin=ci, Cout=F, wp_format=fmt, **geo)
+    lhs, rhs = _dot(dw, V), _dot(y, cv)
+    assert abs(lhs - rhs) <= (5e-5 if fmt == 0 else 3e-4) * max(abs(lhs), abs(rhs), (dw.double().norm() * V.double().norm()).item() * 1e-2), (lhs, rhs)
+    assert abs(_dot(db, torch.ones_like(db)) - y.double().sum().item()) <= 1e-4 * y.double().abs().sum().item()
+
+
+@pytest.fixture(scope="module")
+def full_generator(srk):
+    torch.manual_seed(0)
+    gen = srk.GeneratorRRDB(1, filters=64, num_res_blocks=23, num_upsample=2).cuda()
+    sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=23, num_upsample=2)
+    gen.load_state_dict(sd)
+    return gen, sd
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_full_generator_properties(full_generator, mode):
+    """Full depth (351 convs): batch independence and run-to-run determinism, both bit-exact.  The kernels use no
+    atomics and fixed reduction orders, so any difference would be a race in the LDS pipelines / loader waves."""
+    gen, sd = full_generator
+    gen._engine.precision = mode
+    lr, hr = O.jet_images(4, 1, 256, 256, 77, 4)
+    lr, hr = lr.cuda(), hr.cuda()
+    with torch.no_grad():
+        y = gen(lr)
+        y1 = gen(lr[1:2])
+        assert torch.isfinite(y).all()
+        assert torch.equal(y1, y[1:2])          # image 1 alone == image 1 inside the batch
+    grads = []
+    for _ in range(2):
+        gen.zero_grad(set_to_none=True)
+        out = gen(lr)
+        (out - hr).abs().mean().backward()
+        grads.append([p.grad.clone() for p in gen.parameters() if p.grad is not None])
+    assert len(grads[0]) == 702
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    gen._engine.precision = "f32"
+
+
+def test_full_generator_forward_vs_oracle(full_generator):
+    """F=64, R=23, 4x: HIP forward vs the CPU oracle on identical weights/inputs (BASELINE's 1e-3 bar) in both modes."""
+    gen, sd = full_generator
+    lr, _ = O.jet_images(2, 1, 256, 256, 4321, 4)
+    with torch.no_grad():
+        ref, _ = O.generator_forward(sd, lr, 23, 2, 0.2, training=True)
+        for mode, tol in (("f32", 2e-5), ("bf16x3", 1e-4)):
+            gen._engine.precision = mode
+            y = gen(lr.cuda()).cpu()
+            err = ((y - ref).abs().max() / ref.abs().max()).item()
+            assert err < tol, (mode, err)
+    gen._engine.precision = "f32"
