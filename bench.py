@@ -42,7 +42,7 @@ def parse():
                     help="gan = BASELINE.json's metric (full G+D iteration, configs[2]); g_only = warm-up iteration (configs[1])")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
     ap.add_argument("--res-blocks", type=int, default=23)
-    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", "f32"), choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
                     help="f32 (default, headline): exact-fp32 MFMA everywhere.  bf16x3: opt-in split-bf16 MFMA mode")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra opt-in bf16x3 measurement and the full-size parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -78,7 +78,8 @@ typedef struct srk_conv_args {
   const float* mask; int32_t m_ldc, m_coff; float mask_slope;
   int32_t wp_format;        /* 0: fp32 fragments, exact-fp32 MFMA (default).  1: split-bf16 ("bf16x3") fragments from
                                srk_pack_weights_bf16x3 -> 3 bf16 MFMAs per product, fp32 accumulate, ~2^-16 relative
-                               operand precision; opt-in, needs srk_conv3x3_bf16x3_supported() */
+                               operand precision; opt-in, needs srk_conv3x3_bf16x3_supported().
+                               2: same packed weights, plain bf16 operands (hi parts only; mixed precision) */
 } srk_conv_args;
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
@@ -106,7 +107,8 @@ typedef struct srk_wgrad_args {
   int32_t accumulate;
   void* workspace; size_t workspace_bytes;
   int32_t precision;        /* 0: exact fp32 MFMA (default).  1: split-bf16 operands, 3 bf16 MFMAs per product, fp32
-                               accumulate (opt-in; stride 1, Cin % 8 == 0, Cout % 8 == 0, 16-byte addressable views) */
+                               accumulate (opt-in; stride 1, Cin % 8 == 0, Cout % 8 == 0, 16-byte addressable views).
+                               2: plain bf16 operands (hi parts only), fp32 accumulate */
 } srk_wgrad_args;
 
 int srk_conv3x3_wgrad(const srk_wgrad_args* a, void* stream);

@@ -155,8 +155,8 @@ class KernelTimer:
 
 def _conv_kernel_name(a) -> str:
     """Mirror of the dispatch in srk_conv.hip (srk_conv3x3)."""
-    if a.wp_format == 1:
-        return f"conv3x3_bf16x3_kernel<{a.in_mode}>"
+    if a.wp_format in (1, 2):
+        return f"conv3x3_bf16x3_kernel<{a.in_mode}, {3 if a.wp_format == 1 else 1}>"
     vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
     bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
     mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
@@ -248,7 +248,7 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
     ws = _workspace(nbytes.value, problems[0]["x"].t.device)
     arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket((f"wgrad_bf16x3_kernel<{dy_mode}>+reduce" if precision == 1 else f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce"), flops)
+        e0, e1 = KernelTimer.bracket((f"wgrad_bf16x3_kernel<{dy_mode}, {3 if precision == 1 else 1}>+reduce" if precision in (1, 2) else f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce"), flops)
         e0.record()
         check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
         e1.record()

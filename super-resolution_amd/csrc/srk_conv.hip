@@ -503,9 +503,11 @@ static int g_use_lw = -1;   // SRK_CONV_LW=0 disables the loader-wave kernels (A
 
 template <int BN, int S, int MODE, bool VEC, int MT>
 int launch(const srk_conv_args& a, hipStream_t st) {
-  if constexpr (S == 1 && VEC && MT == 2 && BN == 64 && MODE != SRK_IN_ZERO_UPSAMPLE) {
-    if (g_use_lw < 0) { const char* e = getenv("SRK_CONV_LW"); g_use_lw = (e && e[0] == '0') ? 0 : 1; }
-    if (g_use_lw) return launch_lw<BN, MODE>(a, st);
+  if constexpr (S == 1 && VEC && MT == 2 && MODE != SRK_IN_ZERO_UPSAMPLE) {
+    // SRK_CONV_LW: 0 = never, 1 = 64-channel tiles only (default), 2 = also 32-channel tiles with Cout >= 16
+    if (g_use_lw < 0) { const char* e = getenv("SRK_CONV_LW"); g_use_lw = e ? atoi(e) : 1; }
+    if (g_use_lw >= 1 && BN == 64) return launch_lw<BN, MODE>(a, st);
+    if (g_use_lw >= 2 && BN == 32 && a.Cout >= 16) return launch_lw<BN, MODE>(a, st);
   }
   return launch_k<BN, S, MODE, VEC, MT, false>(a, st);
 }
@@ -530,7 +532,7 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
   if (!pa) return SRK_ERR_BAD_ARG;
   const srk_conv_args& a = *pa;
   hipStream_t st = (hipStream_t)stream;
-  if (a.wp_format == 1) {
+  if (a.wp_format == 1 || a.wp_format == 2) {
     if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return SRK_ERR_BAD_ARG;
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
     if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;

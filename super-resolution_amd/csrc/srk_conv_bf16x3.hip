@@ -30,7 +30,9 @@ constexpr int BBUF4 = XP4 + WP4;                 // 3664 units = 58,624 B
 constexpr int NLOAD = 3;                         // loader waves (4 measured identical: the main loop is not loader-bound)
 constexpr int BTHREADS = 64 * (4 + NLOAD);
 
-template <int MODE>
+// TERMS = 3: split-bf16 (hi*hi + hi*lo + lo*hi);  TERMS = 1: plain bf16 operands (hi*hi only, the lo planes are never
+// written or read) -- mixed precision with fp32 accumulate / fp32 master weights (BASELINE config 4).
+template <int MODE, int TERMS>
 __global__ __launch_bounds__(BTHREADS) void conv3x3_bf16x3_kernel(const srk_conv_args a) {
   constexpr int BN = 64, MT = 2, NTN = 2;
   __shared__ float4 smem[2 * BBUF4];
@@ -103,7 +105,10 @@ __global__ __launch_bounds__(BTHREADS) void conv3x3_bf16x3_kernel(const srk_conv
         xb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvo[i] == OOB ? OOB : xvo[i] + 16, xso, 0));
       }
 #pragma unroll
-      for (int i = 0; i < NWI; ++i) wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo[i], wso, 0));
+      for (int i = 0; i < NWI; ++i) {
+        const int part = ((lane + 64 * (lw + NLOAD * i)) >> 7) & 1;       // [tap][part][h][64]: bit 7 of the piece index
+        if (TERMS == 3 || part == 0) wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo[i], wso, 0));
+      }
 #pragma unroll
       for (int i = 0; i < NXI; ++i) {
         f32x8 v;
@@ -114,17 +119,17 @@ __global__ __launch_bounds__(BTHREADS) void conv3x3_bf16x3_kernel(const srk_conv
           for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * in_slope;
         }
         const bf16x8 hi = __builtin_convertvector(v, bf16x8);
-        const f32x8 hf = __builtin_convertvector(hi, f32x8);
-        const bf16x8 lo = __builtin_convertvector(v - hf, bf16x8);
-        if (xdst[i] >= 0) {
-          dst[xdst[i]] = __builtin_bit_cast(float4, hi);
-          dst[2 * BNHP + xdst[i]] = __builtin_bit_cast(float4, lo);
+        if (xdst[i] >= 0) dst[xdst[i]] = __builtin_bit_cast(float4, hi);
+        if constexpr (TERMS == 3) {
+          const f32x8 hf = __builtin_convertvector(hi, f32x8);
+          const bf16x8 lo = __builtin_convertvector(v - hf, bf16x8);
+          if (xdst[i] >= 0) dst[2 * BNHP + xdst[i]] = __builtin_bit_cast(float4, lo);
         }
       }
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int idx = lane + 64 * (lw + NLOAD * i);
-        dst[XP4 + idx] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
+        if (TERMS == 3 || ((idx >> 7) & 1) == 0) dst[XP4 + idx] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
       }
     };
     stage(0, 0);
@@ -155,18 +160,18 @@ __global__ __launch_bounds__(BTHREADS) void conv3x3_bf16x3_kernel(const srk_conv
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       ah[p][m] = __builtin_bit_cast(bf16x8, base[abase + (4 * m + r) * BIW + s]);
-      al[p][m] = __builtin_bit_cast(bf16x8, base[2 * BNHP + abase + (4 * m + r) * BIW + s]);
+      if constexpr (TERMS == 3) al[p][m] = __builtin_bit_cast(bf16x8, base[2 * BNHP + abase + (4 * m + r) * BIW + s]);
     }
 #pragma unroll
     for (int t = 0; t < NTN; ++t) {
       bh[p][t] = __builtin_bit_cast(bf16x8, base[wbase + (tap * 2 + 0) * 128 + 32 * t]);
-      bl[p][t] = __builtin_bit_cast(bf16x8, base[wbase + (tap * 2 + 1) * 128 + 32 * t]);
+      if constexpr (TERMS == 3) bl[p][t] = __builtin_bit_cast(bf16x8, base[wbase + (tap * 2 + 1) * 128 + 32 * t]);
     }
   };
   auto mfma_tap = [&](int p) {
     // product term outermost: consecutive MFMAs hit different accumulators
 #pragma unroll
-    for (int term = 0; term < 3; ++term)
+    for (int term = 0; term < TERMS; ++term)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -193,9 +198,9 @@ __global__ __launch_bounds__(BTHREADS) void conv3x3_bf16x3_kernel(const srk_conv
     mfma_tap(0);                                 // tap 8
     if (more) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { ah[0][m] = ah[1][m]; al[0][m] = al[1][m]; }
+      for (int m = 0; m < MT; ++m) { ah[0][m] = ah[1][m]; if constexpr (TERMS == 3) al[0][m] = al[1][m]; }
 #pragma unroll
-      for (int t = 0; t < NTN; ++t) { bh[0][t] = bh[1][t]; bl[0][t] = bl[1][t]; }
+      for (int t = 0; t < NTN; ++t) { bh[0][t] = bh[1][t]; if constexpr (TERMS == 3) bl[0][t] = bl[1][t]; }
     }
   }
   conv_epilogue<BN, MT, true>(a, acc, smem, n, oh0, ow0, n0, wv, lane);
@@ -264,8 +269,13 @@ int srk_launch_conv_bf16x3(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, BT_W), tilesH = srk_div_up(a.OH, BT_H);
   const int CoutP = srk_round_up(a.Cout, 32);
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)srk_div_up(CoutP, 64));
-  if (a.in_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL(conv3x3_bf16x3_kernel<SRK_IN_UNSHUFFLE>, grid, dim3(BTHREADS), 0, st, a);
-  else hipLaunchKernelGGL(conv3x3_bf16x3_kernel<SRK_IN_PLAIN>, grid, dim3(BTHREADS), 0, st, a);
+  if (a.wp_format == 2) {
+    if (a.in_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<SRK_IN_UNSHUFFLE, 1>), grid, dim3(BTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16x3_kernel<SRK_IN_PLAIN, 1>), grid, dim3(BTHREADS), 0, st, a);
+  } else {
+    if (a.in_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<SRK_IN_UNSHUFFLE, 3>), grid, dim3(BTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_bf16x3_kernel<SRK_IN_PLAIN, 3>), grid, dim3(BTHREADS), 0, st, a);
+  }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }

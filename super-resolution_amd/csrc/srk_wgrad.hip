@@ -238,7 +238,7 @@ __device__ __forceinline__ wbf16x4 tr_read(const char* p) {
   return __builtin_bit_cast(wbf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)p));
 }
 
-template <int DYMODE>
+template <int DYMODE, int TERMS>
 __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B, float* part, float* pbias) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BW_BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -314,11 +314,13 @@ __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B
         wf32x8 v;
         v[0] = ra[i].x; v[1] = ra[i].y; v[2] = ra[i].z; v[3] = ra[i].w; v[4] = rb[i].x; v[5] = rb[i].y; v[6] = rb[i].z; v[7] = rb[i].w;
         const wbf16x8 hi = __builtin_convertvector(v, wbf16x8);
-        const wf32x8 hf = __builtin_convertvector(hi, wf32x8);
-        const wbf16x8 lo = __builtin_convertvector(v - hf, wbf16x8);
-        const int lo_off = dst[i] < BW_DY_BYTES ? 2 * BW_TP * 64 : 2 * BW_NHP * 64;
         *reinterpret_cast<float4*>(buf + dst[i]) = __builtin_bit_cast(float4, hi);
-        *reinterpret_cast<float4*>(buf + dst[i] + lo_off) = __builtin_bit_cast(float4, lo);
+        if constexpr (TERMS == 3) {
+          const wf32x8 hf = __builtin_convertvector(hi, wf32x8);
+          const wbf16x8 lo = __builtin_convertvector(v - hf, wbf16x8);
+          const int lo_off = dst[i] < BW_DY_BYTES ? 2 * BW_TP * 64 : 2 * BW_NHP * 64;
+          *reinterpret_cast<float4*>(buf + dst[i] + lo_off) = __builtin_bit_cast(float4, lo);
+        }
       }
     };
     if (t_begin < t_end) stage(t_begin, 0);
@@ -364,22 +366,30 @@ __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B
         wbf16x8 ah, al;
         {
           const wbf16x4 h0 = tr_read(buf + a_lane + (16 * kk) * 64), h1 = tr_read(buf + a_lane + (16 * kk + 4) * 64);
-          const wbf16x4 l0 = tr_read(buf + a_lane + A_LO + (16 * kk) * 64), l1 = tr_read(buf + a_lane + A_LO + (16 * kk + 4) * 64);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { ah[j] = h0[j]; ah[4 + j] = h1[j]; al[j] = l0[j]; al[4 + j] = l1[j]; }
+          for (int j = 0; j < 4; ++j) { ah[j] = h0[j]; ah[4 + j] = h1[j]; }
+          if constexpr (TERMS == 3) {
+            const wbf16x4 l0 = tr_read(buf + a_lane + A_LO + (16 * kk) * 64), l1 = tr_read(buf + a_lane + A_LO + (16 * kk + 4) * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { al[j] = l0[j]; al[4 + j] = l1[j]; }
+          }
         }
         if (do_bias) {
           accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+          if constexpr (TERMS == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
         }
         wbf16x8 bh[2], bl[2];
         auto ld_b = [&](int pbuf, int tap) {
           const int r = tap / 3, s = tap - 3 * r;
           const char* base = buf + b_lane + ((kk + r) * BW_IW + s) * 64;
           const wbf16x4 h0 = tr_read(base), h1 = tr_read(base + 4 * 64);
-          const wbf16x4 l0 = tr_read(base + B_LO), l1 = tr_read(base + B_LO + 4 * 64);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { bh[pbuf][j] = h0[j]; bh[pbuf][4 + j] = h1[j]; bl[pbuf][j] = l0[j]; bl[pbuf][4 + j] = l1[j]; }
+          for (int j = 0; j < 4; ++j) { bh[pbuf][j] = h0[j]; bh[pbuf][4 + j] = h1[j]; }
+          if constexpr (TERMS == 3) {
+            const wbf16x4 l0 = tr_read(base + B_LO), l1 = tr_read(base + B_LO + 4 * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bl[pbuf][j] = l0[j]; bl[pbuf][4 + j] = l1[j]; }
+          }
         };
         ld_b(0, 0);
 #pragma unroll
@@ -388,8 +398,10 @@ __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B
           if (tap < 8) ld_b(cur ^ 1, tap + 1);
           __builtin_amdgcn_sched_barrier(0);
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cur], acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cur], acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cur], acc[tap], 0, 0, 0);
+          if constexpr (TERMS == 3) {
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cur], acc[tap], 0, 0, 0);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cur], acc[tap], 0, 0, 0);
+          }
         }
       }
     }
@@ -632,17 +644,22 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
   }
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
-  if (a0.precision == 1) {
-    // split-bf16: stride 1, 8-channel slots
+  if (a0.precision == 1 || a0.precision == 2) {
+    // split-bf16 (1) / plain bf16 (2): stride 1, 8-channel slots
     bool ok = vec && a0.stride == 1;
     for (int i = 0; i < n; ++i) {
-      ok = ok && args[i].precision == 1 && (args[i].Cin % 8 == 0) && (args[i].Cout % 8 == 0);
+      ok = ok && args[i].precision == a0.precision && (args[i].Cin % 8 == 0) && (args[i].Cout % 8 == 0);
       if (a0.dy_mode == SRK_IN_UNSHUFFLE) ok = ok && ((args[i].Cout >> 2) % 8 == 0);
     }
     if (!ok) return SRK_ERR_UNSUPPORTED;
     dim3 grid(B.P, B.n_chunks);
-    if (a0.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_UNSHUFFLE>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
-    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+    if (a0.precision == 2) {
+      if (a0.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_UNSHUFFLE, 1>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+      else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN, 1>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+    } else {
+      if (a0.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_UNSHUFFLE, 3>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+      else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN, 3>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
+    }
     SRK_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
     SRK_CHECK_LAUNCH();

@@ -171,7 +171,7 @@ class GeneratorEngine:
         self.tab_f, self.tab_b = [L.PackTable(device, 0), L.PackTable(device, 1)], [L.PackTable(device, 0), L.PackTable(device, 1)]
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
-        bf = self.precision == "bf16x3"
+        bf = self.precision in ("bf16x3", "bf16")
         self._built_precision = self.precision
 
         def fmt_of(K, M):
@@ -253,11 +253,13 @@ class GeneratorEngine:
             b = self.gen.upsampling[3 * u].bias.data
             self.ps_bias[u] = b.view(-1, 4).t().contiguous().view(-1)
 
-    def wf(self, i):
-        return _PackedW(self.flat_f.slices[i], self.fmt_f[i])
+    def wf(self, i):          # wp_format: 0 fp32, 1 split-bf16, 2 plain bf16 (same packing as 1)
+        f = self.fmt_f[i]
+        return _PackedW(self.flat_f.slices[i], 2 if (f == 1 and self.precision == "bf16") else f)
 
     def wb(self, i):
-        return _PackedW(self.flat_b.slices[i], self.fmt_b[i])
+        f = self.fmt_b[i]
+        return _PackedW(self.flat_b.slices[i], 2 if (f == 1 and self.precision == "bf16") else f)
 
     # ------------------------------------------------------------------ building blocks
     def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float):
@@ -294,7 +296,7 @@ class GeneratorEngine:
             conv = getattr(d, f"b{k}")[0]
             probs.append(dict(x=View(D, 0, k * F_), dy=View(E, (5 - k) * F_, F_), dw=grads[conv.weight], db=grads[conv.bias],
                               Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0) * self._grad_scale))
-        wprec = 1 if (self.precision == "bf16x3" and F_ % 8 == 0) else 0
+        wprec = {"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0
         self._on_side(lambda: L.conv3x3_wgrad_batched(probs, N=N, H=H, W=W, OH=H, OW=W, precision=wprec), (D, E))
 
     def _on_side(self, fn, tensors):
@@ -479,7 +481,7 @@ class GeneratorEngine:
         g_h3 = _empty(N, h, w, F_, device=dev)
         L.conv3x3(View(go), self.wb(self.idx["conv3.2"][1]), None, View(g_h3), N=N, H=h, W=w, OH=h, OW=w, Cin=C_, Cout=F_,
                   mask=View(h3), mask_slope=G_SLOPE)
-        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, scale=self._grad_scale, precision=(1 if (self.precision == "bf16x3" and F_ % 8 == 0) else 0))
+        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
         g_cur = _empty(N, h, w, F_, device=dev)
         # the tensor feeding conv3.0 is a LeakyReLU output (last upsample stage) unless final RRDBs / no upsampling sit between
         mask_v = None
@@ -503,7 +505,7 @@ class GeneratorEngine:
             xin = ups[u - 1] if u > 0 else saved["feat"]
             xin_v = View(xin) if xin.shape[3] == F_ else View(xin, 0, F_)
             L.conv3x3_wgrad(xin_v, View(g_cur), grads[conv.weight], grads[conv.bias], N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=F_, Cout=4 * F_,
-                            dy_mode=L.IN_UNSHUFFLE, scale=self._grad_scale, precision=(1 if (self.precision == "bf16x3" and F_ % 8 == 0) else 0))
+                            dy_mode=L.IN_UNSHUFFLE, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
             g_prev = _empty(N, hh, ww, F_, device=dev)
             L.conv3x3(View(g_cur), self.wb(self.idx[f"up{u}"][1]), None, View(g_prev), N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=4 * F_, Cout=F_,
                       in_mode=L.IN_UNSHUFFLE, mask=(View(ups[u - 1]) if u > 0 else None), mask_slope=G_SLOPE)
@@ -514,7 +516,7 @@ class GeneratorEngine:
         bufs = saved["bufs"]
         D0 = bufs[0]
         trunk_v = View(trunk) if trunk.shape[3] == F_ else View(trunk, 0, F_)
-        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_, scale=self._grad_scale, precision=(1 if (self.precision == "bf16x3" and F_ % 8 == 0) else 0))
+        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
         g_trunk = _empty(N, H, W, F_, device=dev)
         L.conv3x3(View(g_feat), self.wb(self.idx["conv2"][1]), None, View(g_trunk), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
         self._reduce_bucket("tail")

@@ -268,3 +268,24 @@ def test_hipgraph_replay_matches_eager(srk):
         for ta, tb in zip(a, b):
             assert torch.equal(ta, tb)
     gen._engine.use_graphs = False
+
+
+def test_plain_bf16_mixed_precision_mode(srk, golden_dir):
+    """engine.precision = "bf16" (BASELINE config 4 style mixed precision: bf16 MFMA operands, fp32 accumulate, fp32
+    master weights and activations in HBM).  8-bit mantissas: loose bounds; the point is that the path runs, is
+    deterministic and stays close to fp32."""
+    d = np.load(os.path.join(golden_dir, "G4b_gen_c3_f16_r1_u1.npz"))       # 3-channel (photographic-style) generator
+    c, f, r, u = [int(v) for v in d["cfg"]]
+    gen = srk.GeneratorRRDB(c, filters=f, num_res_blocks=r, num_upsample=u, res_scale=float(d["res_scale"])).cuda()
+    gen._engine.precision = "bf16"
+    _load_closed_form(gen, float(d["gain"]))
+    x = torch.from_numpy(d["x"]).cuda()
+    y = gen(x)
+    ref = torch.from_numpy(d["y_train"])
+    assert rel(y.detach().cpu(), ref) < 3e-2
+    (y - torch.from_numpy(d["target"]).cuda()).abs().mean().backward()
+    g1 = gen.conv2.weight.grad.clone()
+    assert rel(g1.cpu(), torch.from_numpy(d["grad.conv2.weight"])) < 0.1
+    gen.zero_grad()
+    y2 = gen(x)
+    assert torch.equal(y2, y)
