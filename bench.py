@@ -83,13 +83,34 @@ def cpu_baseline(res_blocks, workload):
     params = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999))
     lr, hr = O.jet_images(n, 1, HR, HR, 1234, FACTOR)
+    dsd, optD = [], []
+    if workload == "gan":
+        g = torch.Generator().manual_seed(1)
+        for k in range(2):
+            d = {}
+            for name, shp in O.discriminator_state_shapes().items():
+                fan = shp[1] * 9 if len(shp) == 4 else 16 * 9
+                d[name] = ((torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(fan)).requires_grad_(True)
+            dsd.append(d)
+            optD.append(torch.optim.Adam(list(d.values()), lr=2e-4, betas=(0.9, 0.999)))
     times = []
     for it in range(5):
         t0 = time.perf_counter()
         opt.zero_grad()
-        y, _ = O.generator_forward(params, lr, res_blocks, 2, 0.2, training=True)
-        O.warmup_loss(y, hr).backward()
-        opt.step()
+        y, srs = O.generator_forward(params, lr, res_blocks, 2, 0.2, training=True)
+        if workload == "gan":                         # esrgan.py:457-626 restated (oracle/esrgan_oracle.py)
+            lG, _ = O.g_phase_loss([y, srs], hr, lr, dsd, FACTOR)
+            lG.backward()
+            opt.step()
+            for k in range(2):
+                optD[k].zero_grad()
+                lD, _ = O.d_phase_loss(dsd[k], hr, [y, srs][k].detach(), torch.rand(n, 1, 1, 1), 0.01)
+                lD.backward()
+                if lD.item() > 0.001:
+                    optD[k].step()
+        else:
+            O.warmup_loss(y, hr).backward()
+            opt.step()
         times.append(time.perf_counter() - t0)
         print(f"[cpu_baseline] iter {it}: {times[-1]:.1f} s on {cores} threads", file=sys.stderr, flush=True)
         if it >= 1 and sum(times) > 25.0:
@@ -97,8 +118,9 @@ def cpu_baseline(res_blocks, workload):
     timed = times[1:]
     dt = sum(timed) / len(timed)
     return {"value": n * HR * HR / dt, "unit": "HR-px/s", "cores": cores, "kind": "port",
-            "sample": f"G-only step (fwd+L1+bwd+Adam) of the same generator, batch {n}, 1 warm-up + {len(timed)} timed iters, "
-                      f"{dt*1e3:.0f} ms/iter, torch CPU fp32"}
+            "sample": ("full G+D iteration (two patch discriminators, relativistic BCE, gradient penalty, 3x Adam)" if workload == "gan"
+                       else "G-only step (fwd+L1+bwd+Adam)") +
+                      f" of the same generator, batch {n}, 1 warm-up + {len(timed)} timed iters, {dt*1e3:.0f} ms/iter, torch CPU fp32"}
 
 
 def full_size_parity(sr, res_blocks, dev):

@@ -576,7 +576,10 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   // problems: the second workgroup per CU hides more than the extra partial-sum traffic costs.)
   static int small_target = -1;
   if (small_target < 0) { const char* e = getenv("SRK_WGRAD_SMALL_TARGET"); small_target = e ? atoi(e) : 512; }
+  static int tiny_target = -1;        // single-chunk problems with <= 32 input channels (discriminator layers)
+  if (tiny_target < 0) { const char* e = getenv("SRK_WGRAD_TINY_TARGET"); tiny_target = e ? atoi(e) : 512; }
   int target = (nc <= 2 ? small_target : 512) / nc;
+  if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
   // split finer than 8 tiles per workgroup
