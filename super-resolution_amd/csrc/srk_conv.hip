@@ -532,6 +532,9 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
   if (!pa) return SRK_ERR_BAD_ARG;
   const srk_conv_args& a = *pa;
   hipStream_t st = (hipStream_t)stream;
+  // the kernels address one input image through a 32-bit buffer resource (out-of-range lanes read 0)
+  if (a.H > 0 && a.W > 0 && a.x_ldc > 0 &&
+      (long)a.H * a.W * a.x_ldc * 4 * (a.in_mode == SRK_IN_UNSHUFFLE ? 4 : 1) > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
   if (a.wp_format == 1 || a.wp_format == 2) {
     if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return SRK_ERR_BAD_ARG;
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;

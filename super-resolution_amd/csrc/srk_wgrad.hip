@@ -50,7 +50,16 @@ struct WBatch {
 
 constexpr size_t CHUNK_FLOATS = 9 * 64 * 64;
 
-template <int S, int DYMODE, bool VEC>
+// KSP ("k-split") > 1 is used when every problem of the launch has Cout <= 32 or Cin <= 32 (discriminator layers):
+// a chunk then has only 1 or 2 live 32x32 wave tiles, so instead of idling the other waves, KSP waves share one dW tile
+// and split the PIXELS of every staged tile (contiguous k-step ranges); they are summed through LDS, in fixed order,
+// before the partial block is written.  KSP = 4: Cout <= 32 and Cin <= 32;  KSP = 2: one of the two.
+//
+// VEC staging uses buffer loads (per-image resource, out-of-range lanes point past num_records and read 0): no
+// divergent branches, so the compiler keeps all loads of a tile in flight instead of waiting after each one.
+constexpr unsigned W_OOB = 0x80000000u;
+
+template <int S, int DYMODE, bool VEC, int KSP>
 __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch B, float* part, float* pbias) {
   using G = WGeo<S>;
   __shared__ float smem[G::TP * 64 + G::NHP * 64];
@@ -59,15 +68,21 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int hl = lane >> 5, l32 = lane & 31;
-  const int wa = wv & 1, wb = wv >> 1;
   const int p = blockIdx.x, chunk = blockIdx.y;
   const WProb& a = B.prob[B.c_prob[chunk]];
   const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
   const int cin0 = cy * 64, cout0 = cz * 64;
+  int wa = wv & 1, wb = wv >> 1, ks = 0;                  // ks: this wave's pixel slice
+  if (KSP == 4) { wa = 0; wb = 0; ks = wv; }
+  if (KSP == 2) {
+    ks = wv >> 1;
+    if (cin0 + 32 < a.Cin) { wa = 0; wb = wv & 1; } else { wa = wv & 1; wb = 0; }
+  }
   const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
   const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
   const int Cps = a.Cout >> 2;
   const float in_slope = a.in_slope;
+  constexpr int KQ = (G::TP / 2) / KSP;                   // k-steps [ks * KQ, ks * KQ + KQ) of every tile
 
   f32x16 acc[9];
 #pragma unroll
@@ -86,6 +101,11 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
   constexpr int NDY = (G::TP * 16 + SRK_THREADS - 1) / SRK_THREADS;
   constexpr int NXH = (G::NHP * 16 + SRK_THREADS - 1) / SRK_THREADS;
   float4 rdy[NDY], rxh[NXH];
+  const long x_img = (long)B.H * B.W * a.x_ldc;
+  const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
+  const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
+  const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
+  const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
   auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % B.tilesW; tt /= B.tilesW;
@@ -93,52 +113,70 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
     const int n = tt;
     const int oh0 = ty * G::TH, ow0 = tx * WTW;
     const int ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;
+    if constexpr (VEC) {
+      __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+      __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int idx = tid + u * SRK_THREADS;
-      const int px = idx >> 4, c4 = idx & 15;
-      const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
-      const int co = cout0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < G::TP * 16 && oh < B.OH && ow < B.OW && co < a.Cout) {
-        const float* src;
+      for (int u = 0; u < NDY; ++u) {
+        const int idx = tid + u * SRK_THREADS;
+        const int px = idx >> 4, c4 = idx & 15;
+        const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
+        const int co = cout0 + 4 * c4;
+        unsigned off;
         if (DYMODE == SRK_IN_UNSHUFFLE) {
           const int ij = co / Cps, c = co - ij * Cps;
-          src = a.dy + ((long)(n * 2 * B.OH + 2 * oh + (ij >> 1)) * (2 * B.OW) + 2 * ow + (ij & 1)) * a.dy_ldc + a.dy_coff + c;
+          off = (unsigned)((((2 * oh + (ij >> 1)) * (2 * B.OW) + 2 * ow + (ij & 1)) * a.dy_ldc + c) * 4);
         } else {
-          src = a.dy + ((long)(n * B.OH + oh) * B.OW + ow) * a.dy_ldc + a.dy_coff + co;
+          off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + co) * 4);
         }
-        if (VEC) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
+        const bool ok = idx < G::TP * 16 && oh < B.OH && ow < B.OW && co < a.Cout;
+        rdy[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dr, ok ? off : W_OOB, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < NXH; ++u) {
+        const int idx = tid + u * SRK_THREADS;
+        const int hp = idx >> 4, c4 = idx & 15;
+        const int hy = hp / G::IW, hx = hp - hy * G::IW;
+        const int ih = ih0 + hy, iw = iw0 + hx;
+        const int ci = cin0 + 4 * c4;
+        const bool ok = idx < G::NHP * 16 && ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin;
+        const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
+        rxh[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? off : W_OOB, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NDY; ++u) {
+        const int idx = tid + u * SRK_THREADS;
+        const int px = idx >> 4, c4 = idx & 15;
+        const int oh = oh0 + px / WTW, ow = ow0 + px % WTW;
+        const int co = cout0 + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < G::TP * 16 && oh < B.OH && ow < B.OW && co < a.Cout) {
+          const float* src = a.dy + ((long)(n * B.OH + oh) * B.OW + ow) * a.dy_ldc + a.dy_coff + co;
           v.x = src[0];
           if (co + 1 < a.Cout) v.y = src[1];
           if (co + 2 < a.Cout) v.z = src[2];
           if (co + 3 < a.Cout) v.w = src[3];
         }
+        rdy[u] = v;
       }
-      rdy[u] = v;
-    }
 #pragma unroll
-    for (int u = 0; u < NXH; ++u) {
-      const int idx = tid + u * SRK_THREADS;
-      const int hp = idx >> 4, c4 = idx & 15;
-      const int hy = hp / G::IW, hx = hp - hy * G::IW;
-      const int ih = ih0 + hy, iw = iw0 + hx;
-      const int ci = cin0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < G::NHP * 16 && ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
-        const float* src = a.x + ((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff + ci;
-        if (VEC) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
+      for (int u = 0; u < NXH; ++u) {
+        const int idx = tid + u * SRK_THREADS;
+        const int hp = idx >> 4, c4 = idx & 15;
+        const int hy = hp / G::IW, hx = hp - hy * G::IW;
+        const int ih = ih0 + hy, iw = iw0 + hx;
+        const int ci = cin0 + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < G::NHP * 16 && ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci < a.Cin) {
+          const float* src = a.x + ((long)(n * B.H + ih) * B.W + iw) * a.x_ldc + a.x_coff + ci;
           v.x = src[0];
           if (ci + 1 < a.Cin) v.y = src[1];
           if (ci + 2 < a.Cin) v.z = src[2];
           if (ci + 3 < a.Cin) v.w = src[3];
         }
+        rxh[u] = v;
       }
-      rxh[u] = v;
     }
   };
   auto store_tile = [&]() {
@@ -159,9 +197,11 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
     }
   };
 
-  // per-lane LDS bases; inside a tile every k-step is a compile-time offset from them (pixel 2kk + hl)
-  const float* abase = dys + hl * 64 + 32 * wa + l32;
-  const float* bbase = xs + (hl * S) * 64 + 32 * wb + l32;
+  // per-lane LDS bases; inside a tile every k-step is a compile-time offset from them (pixel 2(kk0 + kk) + hl).
+  // KQ is a multiple or a divisor of the 8 k-steps of a tile row, so kk0 + kk splits into row/column additively.
+  const int kk0 = ks * KQ;
+  const float* abase = dys + (2 * kk0 + hl) * 64 + 32 * wa + l32;
+  const float* bbase = xs + (((kk0 / (WTW / 2)) * S) * G::IW + (2 * (kk0 % (WTW / 2)) + hl) * S) * 64 + 32 * wb + l32;
 
   if (t_begin < t_end) load_tile(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -173,7 +213,7 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       // software-pipelined k-steps: operands of k-step kk+1 are read from LDS before the 9 MFMAs of kk issue
       float av[2], bv[2][9];
       auto ld_k = [&](int p, int kk) {
-        const int py = kk / (WTW / 2), pc = kk % (WTW / 2);          // pixel 2kk + hl = (row py, col 2pc + hl)
+        const int py = kk / (WTW / 2), pc = kk % (WTW / 2);
         av[p] = abase[(2 * kk) * 64];
         const float* xr0 = bbase + ((py * S) * G::IW + 2 * pc * S) * 64;
 #pragma unroll
@@ -184,9 +224,9 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       };
       ld_k(0, 0);
 #pragma unroll
-      for (int kk = 0; kk < G::TP / 2; ++kk) {
+      for (int kk = 0; kk < KQ; ++kk) {
         const int cur = kk & 1;
-        if (kk + 1 < G::TP / 2) ld_k(cur ^ 1, kk + 1);
+        if (kk + 1 < KQ) ld_k(cur ^ 1, kk + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (do_bias) bsum += av[cur];
 #pragma unroll
@@ -197,8 +237,37 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
     __syncthreads();
   }
 
+  if (KSP > 1) {
+    // fixed-order sum of the pixel slices: slices 1.. park three taps at a time in LDS ([slot][tap][reg][lane], free
+    // after the loop's closing barrier), slice 0 adds them.  Branches are workgroup-uniform or barrier-free.
+    constexpr int NL = 4 / KSP;                               // live wave tiles per chunk
+    const int tl = KSP == 2 ? (wv & 1) : 0;                   // this wave's live-tile index
+    for (int r3 = 0; r3 < 3; ++r3) {
+      if (ks > 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) smem[((((ks - 1) * NL + tl) * 3 + t) * 16 + reg) * 64 + lane] = acc[3 * r3 + t][reg];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int q = 1; q < KSP; ++q)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[3 * r3 + t][reg] += smem[((((q - 1) * NL + tl) * 3 + t) * 16 + reg) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (ks > 0) smem[9216 + ((ks - 1) * NL + tl) * 64 + lane] = bsum;
+    __syncthreads();
+    if (ks == 0)
+#pragma unroll
+      for (int q = 1; q < KSP; ++q) bsum += smem[9216 + ((q - 1) * NL + tl) * 64 + lane];
+  }
   // ---- write partial block: part[p][chunk][tap][64 cout][64 cin]
-  if (active) {
+  if (active && ks == 0) {
     float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -208,7 +277,7 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
         dst[(tap * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = acc[tap][reg];
       }
   }
-  if (do_bias) {
+  if (do_bias && ks == 0) {
     const float tot = bsum + __shfl_xor(bsum, 32);
     if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
@@ -467,6 +536,42 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
   }
 }
 
+// First stage for launches with many pixel-splits (P >= 64: the discriminator layers, 1-2 chunks x 512 splits).  The
+// single-stage reduction above walks P partials serially per thread from only 64 workgroups, i.e. it is pure HBM
+// latency (73 us at P = 512).  Here grid.z = Z slices of P are summed concurrently into Z partial blocks of the SAME
+// layout, which the kernel above then finishes with P := Z.  Fixed order in both stages (deterministic).
+__global__ __launch_bounds__(576) void wgrad_prereduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias,
+                                                              float* __restrict__ part2, float* __restrict__ pbias2, int per) {
+  const int chunk = blockIdx.y, ol = blockIdx.x, z = blockIdx.z, t = threadIdx.x;
+  const WProb& a = B.prob[B.c_prob[chunk]];
+  const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
+  if (cz * 64 + ol >= a.Cout) return;
+  const int tap = t >> 6, cl = t & 63;
+  const int p0 = z * per, p1 = (p0 + per < B.P) ? p0 + per : B.P;
+  const size_t stride = (size_t)B.n_chunks * CHUNK_FLOATS;
+  const size_t off = (size_t)chunk * CHUNK_FLOATS + (tap * 64 + ol) * 64 + cl;
+  if (cy * 64 + cl < a.Cin) {
+    const float* src = part + off;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += src[(size_t)(p + j) * stride];
+    }
+    for (; p < p1; ++p) s[0] += src[(size_t)p * stride];
+    part2[(size_t)z * stride + off] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  }
+  if (a.db && cy == 0 && t < 64) {
+    float v = 0.f;
+    for (int q = p0 + t; q < p1; q += 64) v += pbias[((size_t)q * B.n_chunks + chunk) * 64 + ol];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+    if (t == 0) pbias2[((size_t)z * B.n_chunks + chunk) * 64 + ol] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Cin == 1 (the image-side convs: discriminator model.0, generator conv1; models.py:63,142 with channels=1).
 // dW[o][0][tap] = sum_px DY[px][o] * x[px + tap] has only 9*Cout outputs and one input plane, so the MFMA tiling
@@ -555,6 +660,9 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
     if (!a.x || !a.dy || !a.dw || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
     if (a.N != a0.N || a.H != a0.H || a.W != a0.W || a.OH != a0.OH || a.OW != a0.OW || a.stride != a0.stride || a.dy_mode != a0.dy_mode)
       return SRK_ERR_UNSUPPORTED;
+    // one image of x / dy is addressed through a 32-bit buffer resource
+    if ((long)a.H * a.W * a.x_ldc * 4 > 0x7fffffffL || (long)a.OH * a.OW * a.dy_ldc * 4 * (a.dy_mode == SRK_IN_UNSHUFFLE ? 4 : 1) > 0x7fffffffL)
+      return SRK_ERR_UNSUPPORTED;
     if (a.dy_mode == SRK_IN_UNSHUFFLE && (a.stride != 1 || (a.Cout & 3) || ((a.Cout >> 2) & 3))) return SRK_ERR_UNSUPPORTED;
     WProb& p = B.prob[i];
     p.x = a.x; p.dy = a.dy; p.dw = a.dw; p.db = a.db;
@@ -583,7 +691,10 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
   // split finer than 8 tiles per workgroup
-  const int maxP = B.total_tiles / 8 > 0 ? B.total_tiles / 8 : 1;
+  static int min_tpb_small = -1;       // ... except for small problems (<= 4096 tiles), which are latency- not traffic-bound
+  if (min_tpb_small < 0) { const char* e = getenv("SRK_WGRAD_MIN_TPB"); min_tpb_small = e ? atoi(e) : 2; if (min_tpb_small < 1) min_tpb_small = 1; }
+  const int min_tpb = B.total_tiles <= 4096 ? min_tpb_small : 8;
+  const int maxP = B.total_tiles / min_tpb > 0 ? B.total_tiles / min_tpb : 1;
   if (target > maxP) target = maxP;
   int P = B.total_tiles < target ? B.total_tiles : target;
   B.tpb = srk_div_up(B.total_tiles, P);
@@ -593,9 +704,38 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
 
 bool use_c1(const WBatch& B) { return B.n_prob == 1 && B.prob[0].Cin == 1 && B.dy_mode == SRK_IN_PLAIN; }
 
+// number of first-stage slices of the partial-block reduction (0 = single stage)
+int reduce_slices(const WBatch& B) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("SRK_WGRAD_REDUCE2"); env = e ? atoi(e) : 1; }
+  if (!env || B.P < 64) return 0;
+  int z = B.P / 32;
+  return z > 16 ? 16 : z;
+}
+
 size_t ws_bytes(const WBatch& B) {
   if (use_c1(B)) return (size_t)C1_BLOCKS * srk_div_up(B.prob[0].Cout, C1_CG) * C1_VALS * sizeof(float);
-  return ((size_t)B.P * B.n_chunks * CHUNK_FLOATS + (size_t)B.P * B.n_chunks * 64) * sizeof(float);
+  return ((size_t)(B.P + reduce_slices(B)) * B.n_chunks * (CHUNK_FLOATS + 64)) * sizeof(float);
+}
+
+// sums the P partial blocks (and bias partials) into dW / db
+int launch_reduce(const WBatch& B, float* part, float* pbias, hipStream_t st) {
+  const int Z = reduce_slices(B);
+  if (Z == 0) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
+    SRK_CHECK_LAUNCH();
+    return SRK_OK;
+  }
+  float* part2 = pbias + (size_t)B.P * B.n_chunks * 64;
+  float* pbias2 = part2 + (size_t)Z * B.n_chunks * CHUNK_FLOATS;
+  const int per = srk_div_up(B.P, Z);
+  hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3(64, B.n_chunks, Z), dim3(576), 0, st, B, (const float*)part, (const float*)pbias, part2, pbias2, per);
+  SRK_CHECK_LAUNCH();
+  WBatch B2 = B;
+  B2.P = srk_div_up(B.P, per);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B2, (const float*)part2, (const float*)pbias2);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
 }
 
 bool is_vec(const srk_wgrad_args& a) {
@@ -606,11 +746,28 @@ bool is_vec(const srk_wgrad_args& a) {
 template <int S, int DYMODE, bool VEC>
 int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
   dim3 grid(B.P, B.n_chunks);
-  hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+  // pixel-split factor: 4 if every problem has Cout <= 32 and Cin <= 32, 2 if one of the two holds for every problem
+  int ksp = 1;
+  if (DYMODE == SRK_IN_PLAIN) {
+    bool all4 = true, all2 = true;
+    for (int i = 0; i < B.n_prob; ++i) {
+      const bool sa = B.prob[i].Cout <= 32, sb = B.prob[i].Cin <= 32;
+      all4 = all4 && sa && sb;
+      all2 = all2 && (sa || sb);
+    }
+    ksp = all4 ? 4 : (all2 ? 2 : 1);
+    static int ks_env = -1;
+    if (ks_env < 0) { const char* e = getenv("SRK_WGRAD_KSPLIT"); ks_env = e ? atoi(e) : 1; }
+    if (!ks_env) ksp = 1;
+  }
+  if (DYMODE == SRK_IN_PLAIN && ksp == 4)
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+  else if (DYMODE == SRK_IN_PLAIN && ksp == 2)
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+  else
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC, 1>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   SRK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
-  SRK_CHECK_LAUNCH();
-  return SRK_OK;
+  return launch_reduce(B, part, pbias, st);
 }
 
 }  // namespace
@@ -664,9 +821,7 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
       else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN, 3>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
     }
     SRK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
-    SRK_CHECK_LAUNCH();
-    return SRK_OK;
+    return launch_reduce(B, part, pbias, st);
   }
   if (a0.precision != 0) return SRK_ERR_UNSUPPORTED;
   if (a0.dy_mode == SRK_IN_UNSHUFFLE) {

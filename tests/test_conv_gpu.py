@@ -153,7 +153,10 @@ def test_conv_dgrad_unshuffle(U):
 
 @pytest.mark.parametrize("ci,co,h,w,stride,n", [(64, 64, 16, 16, 1, 2), (128, 64, 12, 20, 1, 3), (1, 16, 16, 16, 1, 2),
                                                   (16, 16, 32, 32, 2, 2), (32, 32, 17, 23, 2, 1), (64, 1, 9, 9, 1, 2),
-                                                  (320, 64, 64, 64, 1, 2), (3, 64, 8, 8, 1, 1), (64, 64, 75, 75, 2, 1)])
+                                                  (320, 64, 64, 64, 1, 2), (3, 64, 8, 8, 1, 1), (64, 64, 75, 75, 2, 1),
+                                                  # pixel-split ("KS") variants: 1 or 2 live wave tiles per chunk
+                                                  (16, 32, 33, 40, 1, 2), (32, 64, 20, 24, 2, 2), (64, 32, 20, 24, 1, 1),
+                                                  (48, 24, 11, 13, 2, 2), (128, 32, 16, 16, 1, 1), (16, 96, 16, 16, 2, 1)])
 def test_conv_wgrad(U, ci, co, h, w, stride, n):
     L = U.L
     x = _rand((n, ci, h, w), 22)
