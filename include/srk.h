@@ -168,6 +168,25 @@ int srk_nhwc_to_nchw(const float* x, int x_ldc, int x_coff, float* y, int N, int
 int srk_sum_pool_fwd(const float* x, float* y, int NC, int H, int W, int k, void* stream);
 int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W, int k, void* stream);
 
+/* Flat, self-contained entry points on CANONICAL OIHW fp32 weights (SURVEY.md section 8(b)'s signatures): the weights are
+ * packed into the caller's workspace on `stream`, then the fused kernel above runs.  For callers that do not keep
+ * packed weights alive (one conv at a time from another framework); the training engine uses srk_conv3x3 directly.
+ * dtype: 0 = fp32 (the only one accepted here).  H, W = extent of the conv INPUT x (dx for dgrad); the output extent is
+ * ceil(H/stride).  `residual` (optional) is dense [N,OH,OW,Cout]: y = res_scale * (conv + bias) + residual, the
+ * DenseResidualBlock / RRDB tail (models.py:40,53); it excludes lrelu_slope != 1.  pixel_shuffle_r = 2 folds
+ * nn.PixelShuffle(2) into the store (fwd; y is [N,2H,2W,Cout/4]) or its inverse into the load (dgrad; dy likewise).
+ * Replaces: F.conv2d + LeakyReLU (+ residual) forward and its autograd input-gradient, models.py:19-41,63,67,86-99,142-168. */
+enum { SRK_OP_CONV_FWD = 0, SRK_OP_CONV_DGRAD = 1, SRK_OP_CONV_WGRAD = 2 };
+int srk_workspace_bytes(int op, int N, int H, int W, int Cin, int Cout, int dtype, size_t* out);
+int srk_conv3x3_fwd(const void* x, int ldc_in, int c_in_off, int Cin, const void* w, const void* bias, void* y,
+                    int ldc_out, int c_out_off, int Cout, int N, int H, int W, int stride, float lrelu_slope,
+                    const void* residual, float res_scale, int pixel_shuffle_r, int dtype, void* workspace,
+                    size_t ws_bytes, void* stream);
+int srk_conv3x3_dgrad(const void* dy, int ldc_dy, int c_dy_off, int Cout, const void* w, void* dx, int ldc_dx,
+                      int c_dx_off, int Cin, int N, int H, int W, int stride, int pixel_shuffle_r, int dtype,
+                      void* workspace, size_t ws_bytes, void* stream);
+/* (the weight gradient keeps the struct form above: srk_conv3x3_wgrad / srk_conv3x3_wgrad_batched) */
+
 const char* srk_strerror(int status);
 int srk_version(void);
 

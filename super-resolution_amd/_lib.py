@@ -18,8 +18,10 @@ EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
-    "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_strerror", "srk_version",
+    "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
+    "srk_strerror", "srk_version",
 ]
+OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD = 0, 1, 2
 
 _fp = C.c_void_p
 
@@ -91,6 +93,11 @@ def lib():
         L.srk_nhwc_to_nchw.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
         for name in ("srk_sum_pool_fwd", "srk_sum_pool_bwd"):
             getattr(L, name).argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.srk_workspace_bytes.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_size_t)]
+        L.srk_conv3x3_fwd.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_float, _fp, C.c_float, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
+        L.srk_conv3x3_dgrad.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
         _lib = L
     return _lib
 
@@ -254,6 +261,27 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
         e1.record()
         return
     check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
+
+
+def workspace_bytes(op: int, N, H, W, Cin, Cout, dtype=0) -> int:
+    n = C.c_size_t(0)
+    check(lib().srk_workspace_bytes(op, N, H, W, Cin, Cout, dtype, C.byref(n)), "srk_workspace_bytes")
+    return n.value
+
+
+def conv3x3_fwd_flat(x: "View", w, bias, y: "View", *, N, H, W, Cin, Cout, stride=1, slope=1.0, residual=None, res_scale=1.0, ps=0):
+    """srk_conv3x3_fwd: canonical OIHW weights, packed into a scratch workspace inside the call."""
+    ws = _workspace(workspace_bytes(OP_CONV_FWD, N, H, W, Cin, Cout), w.device)
+    check(lib().srk_conv3x3_fwd(x.t.data_ptr(), x.ldc, x.coff, Cin, w.data_ptr(), ptr(bias), y.t.data_ptr(), y.ldc, y.coff, Cout,
+                                N, H, W, stride, slope, ptr(residual), res_scale, ps, 0, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "srk_conv3x3_fwd")
+
+
+def conv3x3_dgrad_flat(dy: "View", w, dx: "View", *, N, H, W, Cin, Cout, stride=1, ps=0):
+    """srk_conv3x3_dgrad: gradient w.r.t. the conv input (H, W = input extent)."""
+    ws = _workspace(workspace_bytes(OP_CONV_DGRAD, N, H, W, Cin, Cout), w.device)
+    check(lib().srk_conv3x3_dgrad(dy.t.data_ptr(), dy.ldc, dy.coff, Cout, w.data_ptr(), dx.t.data_ptr(), dx.ldc, dx.coff, Cin,
+                                  N, H, W, stride, ps, 0, ws.data_ptr(), ws.numel(), stream_ptr()), "srk_conv3x3_dgrad")
 
 
 def packed_floats(K: int, M: int) -> int:

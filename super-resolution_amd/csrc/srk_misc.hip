@@ -7,17 +7,7 @@ namespace {
 
 // ---------------------------------------------------------------- weight packing
 // work item = one float4 of dst: (q_local, tap, h, m) -> 4 consecutive k.
-__global__ void pack_kernel(const srk_pack_entry* __restrict__ tab, int n, long total) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total) return;
-  // binary search entry with elem_begin <= gid
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].elem_begin <= gid) lo = mid; else hi = mid - 1;
-  }
-  const srk_pack_entry e = tab[lo];
-  long t = gid - e.elem_begin;
+__device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
   const int h = (int)(t & 1); t >>= 1;
@@ -47,6 +37,33 @@ __global__ void pack_kernel(const srk_pack_entry* __restrict__ tab, int n, long 
   }
   float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * 9 + tap) * 2 + h) * Mp + m;
   *d = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void pack_kernel(const srk_pack_entry* __restrict__ tab, int n, long total) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  // binary search entry with elem_begin <= gid
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].elem_begin <= gid) lo = mid; else hi = mid - 1;
+  }
+  const srk_pack_entry e = tab[lo];
+  pack_item(e, gid - e.elem_begin);
+}
+
+// one entry passed by value (the flat entry points below: no device-side table to upload)
+__global__ void pack_one_kernel(const srk_pack_entry e, long total) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < total) pack_item(e, gid);
+}
+
+// bias[o] -> packed PixelShuffle order p = (2i+j)*Cout/4 + c  <-  o = 4c + 2i + j
+__global__ void permute_bias_kernel(const float* __restrict__ b, float* __restrict__ bp, int Cout) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Cout) return;
+  const int Cps = Cout >> 2;
+  bp[p] = b[4 * (p % Cps) + p / Cps];
 }
 
 // ---------------------------------------------------------------- pixel shuffle (standalone)
@@ -213,6 +230,110 @@ extern "C" int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W
   hipLaunchKernelGGL(sum_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, NC, H, W, k);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
+}
+
+// ---------------------------------------------------------------- flat (self-contained) entry points
+// Canonical OIHW weights in, packed into the caller's workspace on the same stream, then the fused conv kernel.
+namespace {
+size_t flat_ws_floats(int K, int M) { return srk_packed_floats(K, M) + (size_t)srk_round_up(M, 32); }
+
+int pack_one(const float* w, float* dst, int Cout, int Cin, bool transpose, bool ps, hipStream_t st) {
+  srk_pack_entry e;
+  memset(&e, 0, sizeof(e));
+  e.src = w; e.dst = dst; e.src_cout = Cout; e.src_cin = Cin; e.transpose = transpose ? 1 : 0; e.c_begin = 0;
+  e.M = transpose ? Cin : Cout; e.k_off = 0; e.k_len = transpose ? Cout : Cin; e.K_total = e.k_len;
+  e.ps = ps ? 1 : 0; e.scale = 1.f; e.fmt = 0;
+  int64_t total = 0;
+  int rc = srk_pack_plan(&e, 1, &total);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e, (long)total);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+}  // namespace
+
+extern "C" int srk_workspace_bytes(int op, int N, int H, int W, int Cin, int Cout, int dtype, size_t* out) {
+  if (!out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SRK_ERR_BAD_ARG;
+  if (dtype != 0) return SRK_ERR_UNSUPPORTED;
+  switch (op) {
+    case SRK_OP_CONV_FWD: *out = flat_ws_floats(Cin, Cout) * sizeof(float); return SRK_OK;
+    case SRK_OP_CONV_DGRAD: *out = flat_ws_floats(Cout, Cin) * sizeof(float); return SRK_OK;
+    case SRK_OP_CONV_WGRAD: {
+      // upper bound over stride 1 / 2 and both dy modes for this geometry
+      size_t best = 0;
+      for (int stride = 1; stride <= 2; ++stride) {
+        srk_wgrad_args a;
+        memset(&a, 0, sizeof(a));
+        a.N = N; a.H = H; a.W = W; a.OH = srk_div_up(H, stride); a.OW = srk_div_up(W, stride); a.Cin = Cin; a.Cout = Cout;
+        a.stride = stride; a.x = a.dy = (const float*)16; a.dw = (float*)16; a.x_ldc = Cin; a.dy_ldc = Cout; a.in_slope = 1.f;
+        size_t b = 0;
+        int rc = srk_conv3x3_wgrad_workspace(&a, &b);
+        if (rc) return rc;
+        if (b > best) best = b;
+      }
+      *out = best;
+      return SRK_OK;
+    }
+    default: return SRK_ERR_BAD_ARG;
+  }
+}
+
+extern "C" int srk_conv3x3_fwd(const void* x, int ldc_in, int c_in_off, int Cin, const void* w, const void* bias, void* y,
+                               int ldc_out, int c_out_off, int Cout, int N, int H, int W, int stride, float lrelu_slope,
+                               const void* residual, float res_scale, int pixel_shuffle_r, int dtype, void* workspace,
+                               size_t ws_bytes, void* stream) {
+  if (!x || !w || !y || !workspace) return SRK_ERR_BAD_ARG;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SRK_ERR_BAD_ARG;
+  if (dtype != 0 || (stride != 1 && stride != 2) || (pixel_shuffle_r != 0 && pixel_shuffle_r != 2)) return SRK_ERR_UNSUPPORTED;
+  if (pixel_shuffle_r == 2 && ((Cout & 3) || stride != 1 || residual)) return SRK_ERR_UNSUPPORTED;
+  if (residual && lrelu_slope != 1.f) return SRK_ERR_UNSUPPORTED;      // models.py:40: the residual conv is linear
+  if (ws_bytes < flat_ws_floats(Cin, Cout) * sizeof(float)) return SRK_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* wp = (float*)workspace;
+  float* bp = wp + srk_packed_floats(Cin, Cout);
+  int rc = pack_one((const float*)w, wp, Cout, Cin, false, pixel_shuffle_r == 2, st);
+  if (rc) return rc;
+  const float* b = (const float*)bias;
+  if (b && pixel_shuffle_r == 2) {
+    hipLaunchKernelGGL(permute_bias_kernel, dim3(srk_div_up(Cout, 256)), dim3(256), 0, st, b, bp, Cout);
+    SRK_CHECK_LAUNCH();
+    b = bp;
+  }
+  srk_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.H = H; a.W = W; a.OH = srk_div_up(H, stride); a.OW = srk_div_up(W, stride); a.Cin = Cin; a.Cout = Cout;
+  a.stride = stride; a.in_mode = SRK_IN_PLAIN; a.ps_out = pixel_shuffle_r == 2;
+  a.x = (const float*)x; a.x_ldc = ldc_in; a.x_coff = c_in_off; a.in_slope = 1.f;
+  a.wp = wp; a.bias = b;
+  a.y = (float*)y; a.y_ldc = ldc_out; a.y_coff = c_out_off;
+  a.alpha = residual ? res_scale : 1.f;
+  if (residual) { a.r1 = (const float*)residual; a.r1_ldc = Cout; a.r1_coff = 0; a.beta1 = 1.f; }
+  a.slope = lrelu_slope; a.mask_slope = 1.f;
+  return srk_conv3x3(&a, stream);
+}
+
+extern "C" int srk_conv3x3_dgrad(const void* dy, int ldc_dy, int c_dy_off, int Cout, const void* w, void* dx, int ldc_dx,
+                                 int c_dx_off, int Cin, int N, int H, int W, int stride, int pixel_shuffle_r, int dtype,
+                                 void* workspace, size_t ws_bytes, void* stream) {
+  if (!dy || !w || !dx || !workspace) return SRK_ERR_BAD_ARG;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SRK_ERR_BAD_ARG;
+  if (dtype != 0 || (stride != 1 && stride != 2) || (pixel_shuffle_r != 0 && pixel_shuffle_r != 2)) return SRK_ERR_UNSUPPORTED;
+  if (pixel_shuffle_r == 2 && ((Cout & 3) || stride != 1)) return SRK_ERR_UNSUPPORTED;
+  if (ws_bytes < flat_ws_floats(Cout, Cin) * sizeof(float)) return SRK_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* wpt = (float*)workspace;
+  int rc = pack_one((const float*)w, wpt, Cout, Cin, true, pixel_shuffle_r == 2, st);
+  if (rc) return rc;
+  srk_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.Cin = Cout; a.Cout = Cin; a.stride = 1;
+  if (stride == 2) { a.H = srk_div_up(H, 2); a.W = srk_div_up(W, 2); a.in_mode = SRK_IN_ZERO_UPSAMPLE; }
+  else { a.H = H; a.W = W; a.in_mode = pixel_shuffle_r == 2 ? SRK_IN_UNSHUFFLE : SRK_IN_PLAIN; }
+  a.OH = H; a.OW = W;
+  a.x = (const float*)dy; a.x_ldc = ldc_dy; a.x_coff = c_dy_off; a.in_slope = 1.f;
+  a.wp = wpt; a.y = (float*)dx; a.y_ldc = ldc_dx; a.y_coff = c_dx_off;
+  a.alpha = 1.f; a.slope = 1.f; a.mask_slope = 1.f;
+  return srk_conv3x3(&a, stream);
 }
 
 extern "C" const char* srk_strerror(int s) {

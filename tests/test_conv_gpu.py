@@ -372,3 +372,64 @@ def test_conv_wgrad_bf16x3_batched_and_unshuffle(U):
     L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(g)), dw, db, N=1, H=8, W=12, OH=8, OW=12, Cin=F2, Cout=4 * F2,
                     dy_mode=L.IN_UNSHUFFLE, precision=1)
     assert U.rel_err(dw.cpu(), wt.grad) < BF_TOL and U.rel_err(db.cpu(), b.grad) < BF_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# flat entry points on canonical OIHW weights (SURVEY.md section 8(b) signatures): srk_conv3x3_fwd / srk_conv3x3_dgrad
+@pytest.mark.parametrize("ci,co,h,w,n,stride,slope,res,ps", [
+    (64, 64, 16, 16, 2, 1, 0.01, False, 0),      # DenseResidualBlock b1 (models.py:24)
+    (320, 64, 16, 16, 1, 1, 1.0, True, 0),       # b5 + 0.2 * out + x (models.py:40)
+    (16, 16, 33, 20, 2, 2, 0.2, False, 0),       # discriminator stride-2 conv (models.py:144)
+    (16, 64, 8, 12, 2, 1, 0.01, False, 2),       # upsampling conv + LeakyReLU + PixelShuffle (models.py:86-89)
+    (1, 16, 16, 16, 2, 1, 1.0, False, 0), (64, 1, 9, 9, 1, 1, 1.0, False, 0)])
+def test_flat_conv_fwd(U, ci, co, h, w, n, stride, slope, res, ps):
+    L = U.L
+    x = _rand((n, ci, h, w), 50)
+    wt = _rand((co, ci, 3, 3), 51, 1.0 / np.sqrt(9 * ci))
+    b = _rand((co,), 52, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b, stride=stride), slope)
+    oh, ow = ref.shape[2:]
+    r = _rand(ref.shape, 53) if res else None
+    if res:
+        ref = 0.2 * ref + r
+    if ps:
+        ref = O.pixel_shuffle(ref, 2)
+    # read a channel slice of a wider buffer, write into a channel slice
+    xb = U.nhwc(x, ldc=ci + 8, coff=4)
+    cy = ref.shape[1]
+    y = torch.full((n, ref.shape[2], ref.shape[3], cy + 4), float("nan"), device="cuda")
+    L.conv3x3_fwd_flat(L.View(xb, 4, ci), wt.cuda(), b.cuda(), L.View(y, 4, cy), N=n, H=h, W=w, Cin=ci, Cout=co, stride=stride,
+                       slope=slope, residual=U.nhwc(r) if res else None, res_scale=0.2, ps=ps)
+    assert U.rel_err(U.nchw(y, 4, cy), ref) < TOL
+    assert torch.isnan(y[..., :4]).all()          # neighbouring channels untouched
+
+
+@pytest.mark.parametrize("ci,co,h,w,n,stride,ps", [(64, 64, 16, 16, 2, 1, 0), (128, 64, 12, 20, 1, 1, 0), (16, 32, 33, 20, 2, 2, 0),
+                                                   (32, 32, 16, 16, 1, 2, 0), (16, 64, 8, 12, 2, 1, 2), (1, 16, 16, 16, 1, 1, 0)])
+def test_flat_conv_dgrad(U, ci, co, h, w, n, stride, ps):
+    L = U.L
+    x = _rand((n, ci, h, w), 60).requires_grad_(True)
+    wt = _rand((co, ci, 3, 3), 61, 1.0 / np.sqrt(9 * ci))
+    y = O.conv3x3(x, wt, None, stride=stride)
+    if ps:
+        y = O.pixel_shuffle(y, 2)
+    g = _rand(y.shape, 62)
+    y.backward(g)
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    L.conv3x3_dgrad_flat(L.View(U.nhwc(g)), wt.cuda(), L.View(dx), N=n, H=h, W=w, Cin=ci, Cout=co, stride=stride, ps=ps)
+    assert U.rel_err(U.nchw(dx), x.grad) < TOL
+
+
+def test_flat_workspace_and_errors(U):
+    L = U.L
+    import ctypes as C
+    assert L.workspace_bytes(L.OP_CONV_FWD, 2, 16, 16, 64, 64) >= L.packed_floats(64, 64) * 4
+    assert L.workspace_bytes(L.OP_CONV_WGRAD, 2, 16, 16, 64, 64) > 0
+    n = C.c_size_t(0)
+    assert L.lib().srk_workspace_bytes(L.OP_CONV_FWD, 2, 16, 16, 64, 64, 1, C.byref(n)) == -2      # dtype != fp32: unsupported
+    assert L.lib().srk_workspace_bytes(7, 2, 16, 16, 64, 64, 0, C.byref(n)) == -1
+    x = torch.zeros(1, 8, 8, 8, device="cuda"); y = torch.zeros(1, 8, 8, 8, device="cuda"); w = torch.zeros(8, 8, 3, 3, device="cuda")
+    ws = torch.zeros(16, device="cuda")
+    rc = L.lib().srk_conv3x3_fwd(x.data_ptr(), 8, 0, 8, w.data_ptr(), None, y.data_ptr(), 8, 0, 8, 1, 8, 8, 1, 1.0, None, 1.0, 0, 0,
+                                 ws.data_ptr(), ws.numel() * 4, None)
+    assert rc == -4                                                                                 # workspace too small
