@@ -78,6 +78,31 @@ def test_generator_vs_oracle_ragged_and_final_blocks(srk):
             assert rel(p.grad.cpu(), sdo[k].grad) < GRAD_TOL, k
 
 
+def test_generator_three_channel_photographic_config(srk):
+    """BASELINE.json configs[4] in small: C=3, F=64, 4x (128->512 style), forward + all gradients vs the oracle in exact fp32,
+    and the reduced-precision MFMA modes (bf16x3 / bf16: this build's counterpart of the config's fp16 path) within their
+    stated tolerances.  C=3 exercises the non-vector staging of conv1 and the Cout=3 tail conv."""
+    gen = srk.GeneratorRRDB(3, filters=64, num_res_blocks=2, num_upsample=2).cuda()
+    sd = O.default_init_generator(11, channels=3, filters=64, num_res_blocks=2, num_upsample=2)
+    gen.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 24, 20, generator=g)
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, x, 2, 2, 0.2, training=True)
+    tgt = torch.rand(yo.shape, generator=g)
+    (yo - tgt).abs().mean().backward()
+    assert yo.shape == (2, 3, 96, 80)
+    for mode, otol, gtol in (("f32", OUT_TOL, GRAD_TOL), ("bf16x3", 1e-4, 1e-3), ("bf16", 3e-2, 2e-1)):
+        gen._engine.precision = mode
+        gen.zero_grad(set_to_none=True)
+        y = gen(x.cuda())
+        assert rel(y.detach().cpu(), yo.detach()) < otol, mode
+        (y - tgt.cuda()).abs().mean().backward()
+        worst = max(rel(p.grad.cpu(), sdo[k].grad) for k, p in gen.named_parameters() if p.grad is not None)
+        assert worst < gtol, (mode, worst)
+    gen._engine.precision = "f32"
+
+
 def test_generator_power_multiplier(srk):
     gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1, power=0.5, multiplier=2.0).cuda()
     sd = _load_closed_form(gen)
