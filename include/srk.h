@@ -168,6 +168,35 @@ int srk_nhwc_to_nchw(const float* x, int x_ldc, int x_coff, float* y, int N, int
 int srk_sum_pool_fwd(const float* x, float* y, int NC, int H, int W, int k, void* stream);
 int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W, int k, void* stream);
 
+/* ---- Optional physics loss heads of the generator phase (esrgan.py:522-547), each ONE fused read pass forward and one
+ * read+write pass backward over dense fp32 tensors; reductions are two-stage, fixed-order (deterministic).  `workspace`
+ * must hold srk_loss_workspace_bytes() bytes.
+ *   srk_sigmoid_*     y = sigmoid(scale*x + shift): softgreater(x,val,sigma,delta) = (sigma, sigma*(delta-val)) and
+ *                     nnz_mask(x,sigma) = (sigma, 0) as stand-alone functions            utils.py:259-261,271-272
+ *   srk_soft_count_*  out[b] = sum_i sigmoid(sigma*(x[b,i]-val))  (hard != 0: count(x > val), the target)
+ *                     = softgreater(x,val,sigma).sum(1).sum(1).sum(1)                    esrgan.py:523-524
+ *   srk_mask_l1_*     out[0] = mean_i |sigmoid(sigma*a_i) - sigmoid(sigma*b_i)| = L1Loss(nnz_mask(a), nnz_mask(b)),
+ *                     gradient w.r.t. a                                                 esrgan.py:527-529
+ *   srk_hitogram_*    t [BC][H][W] -> out[i*f+j] = mean_{bc,p,q} sigmoid(sig*(t[bc,f*p+i,f*q+j]-thr)) (sig <= 0: t)
+ *                     = get_hitogram(t, f, thr, sig); f in {1,2,4,8}                      utils.py:264-268
+ *   srk_soft_hist_*   (positive_only = 1; 0: sum over all i)  out[k] = sum_{x_i>0} sigmoid(sigma(x_i-c_k+d_k/2)) - sigmoid(sigma(x_i-c_k-d_k/2)), K <= 64
+ *                     = DiffableHistogram(binedges, sigma)(x[x > 0])                     models.py:308-342, esrgan.py:533-536 */
+int srk_loss_workspace_bytes(size_t* out);
+int srk_sigmoid_fwd(const float* x, float* y, long n, float scale, float shift, void* stream);
+int srk_sigmoid_bwd(const float* y, const float* gy, float* dx, long n, float scale, void* stream);
+int srk_soft_count_fwd(const float* x, float* out, int B, long per_image, float sigma, float val, int hard, void* workspace,
+                       size_t ws_bytes, void* stream);
+int srk_soft_count_bwd(const float* x, const float* gout, float* dx, int B, long per_image, float sigma, float val, void* stream);
+int srk_mask_l1_fwd(const float* a, const float* b, float* out, long n, float sigma, void* workspace, size_t ws_bytes, void* stream);
+int srk_mask_l1_bwd(const float* a, const float* b, const float* gout, float* da, long n, float sigma, void* stream);
+int srk_hitogram_fwd(const float* t, float* out, int BC, int H, int W, int factor, float thr, float sig, void* workspace,
+                     size_t ws_bytes, void* stream);
+int srk_hitogram_bwd(const float* t, const float* gout, float* dt, int BC, int H, int W, int factor, float thr, float sig, void* stream);
+int srk_soft_hist_fwd(const float* x, long n, const float* centers, const float* delta, int K, float sigma, int positive_only,
+                      float* out, void* workspace, size_t ws_bytes, void* stream);
+int srk_soft_hist_bwd(const float* x, long n, const float* centers, const float* delta, int K, float sigma, int positive_only,
+                      const float* gout, float* dx, void* stream);
+
 /* Flat, self-contained entry points on CANONICAL OIHW fp32 weights (SURVEY.md section 8(b)'s signatures): the weights are
  * packed into the caller's workspace on `stream`, then the fused kernel above runs.  For callers that do not keep
  * packed weights alive (one conv at a time from another framework); the training engine uses srk_conv3x3 directly.

@@ -23,6 +23,11 @@ Reference citations (file:line in /root/reference):
   esrgan.py:416-439 warm-up step              -> warmup_step
   esrgan.py:457-555 G phase                   -> g_phase_loss
   esrgan.py:561-626 D phase                   -> d_phase_loss
+  utils.py:259-272  softgreater / get_hitogram / nnz_mask -> same names
+  models.py:308-342 DiffableHistogram         -> diffable_histogram
+  utils.py:90-113   KLD_hist                  -> kld_hist
+  esrgan.py:434-456 bin edges of the energy histogram -> hist_binedges
+  esrgan.py:522-547 optional loss heads       -> g_phase_loss(heads=...)
 """
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -245,11 +250,68 @@ def warmup_loss(gen_hr: Tensor, hr: Tensor) -> Tensor:
     return (gen_hr - hr).abs().mean()
 
 
+# --------------------------------------------------------------------------- optional physics loss heads
+def softgreater(x: Tensor, val, sigma=5000, delta=0) -> Tensor:
+    """utils.py:259-261."""
+    return torch.sigmoid(sigma * (x - val + delta))
+
+
+def nnz_mask(x: Tensor, sigma=5e4) -> Tensor:
+    """utils.py:271-272."""
+    return torch.sigmoid(sigma * x)
+
+
+def get_hitogram(t: Tensor, factor: int, threshold=.1, sig=80) -> Tensor:
+    """utils.py:264-268: cut [B,C,H,W] into factor x factor super-pixels, stack them on the batch axis, average the
+    (soft) hit indicator over batch and channel -> [factor, factor]."""
+    blocks = torch.cat(torch.split(torch.cat(torch.split(t, factor, -2)), factor, -1))
+    if sig > 0:
+        return torch.sigmoid(sig * (blocks - threshold)).mean((0, 1))
+    return blocks.mean((0, 1))
+
+
+def diffable_histogram(x: Tensor, binedges, sigma) -> Tensor:
+    """models.py:308-342 with a sequence of bin edges (the form esrgan.py:454 builds), batchwise=False: [*] -> [1, K]."""
+    edges = torch.as_tensor(binedges, dtype=torch.float64)
+    delta = (edges[1:] - edges[:-1]).float()[None, :]
+    centers = edges[:-1].float() + .5 * delta
+    v = x.reshape(1, -1)
+    v = v[:, None, :] - centers[..., None]
+    v = torch.sigmoid(sigma * (v + delta[..., None] / 2)) - torch.sigmoid(sigma * (v - delta[..., None] / 2))
+    return v.sum(2)
+
+
+def kld_hist(q_entries: Tensor, p_entries: Tensor, binedges) -> Tensor:
+    """utils.py:90-113."""
+    edges = torch.as_tensor(binedges)
+    binsizes = (edges[1:] - edges[:-1]).float()
+    n_p, n_q = p_entries.sum().float(), q_entries.sum().float()
+    p = p_entries * binsizes / n_p
+    q = ((q_entries + 1e-6) * binsizes / n_q).log()
+    return F.kl_div(q, p, reduction='sum') / binsizes.mean()
+
+
+def hist_binedges(nnz, bins: int, power: float = 1.0):
+    """esrgan.py:441-452: bin edges from the non-zero HR pixel values collected during warm-up (90 % quantile cut,
+    k-means cluster centres as bin centres).  ``nnz``: 1-D numpy array.  Note esrgan.py:448 sorts the UNPOWERED values."""
+    import numpy as np
+    from sklearn.cluster import KMeans
+    nnz = np.asarray(nnz)
+    c, b = np.histogram(nnz ** power, 100)
+    e_max = b[(np.cumsum(c) > len(nnz ** power) * .9).argmax()]
+    sorted_nnz = np.sort(nnz)
+    sorted_nnz = sorted_nnz[sorted_nnz <= e_max]
+    k_mean = KMeans(n_clusters=bins, random_state=0).fit(sorted_nnz.reshape(-1, 1))
+    centers = np.sort(k_mean.cluster_centers_.flatten())
+    return np.array([0, *(np.diff(centers) / 2 + centers[:-1]), e_max])
+
+
 def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Sequence[dict],
                  factor: int, scaling_power: float = 1.0, lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1,
-                 d_channels=(16, 32, 32, 64)):
-    """esrgan.py:468-552 at default flags (relativistic, hr+lr+adv terms only).
+                 d_channels=(16, 32, 32, 64), heads: Optional[dict] = None):
+    """esrgan.py:468-552 (relativistic; hr+lr+adv terms, plus the optional heads of esrgan.py:522-547 when ``heads`` =
+    dict(lambda_nnz, lambda_mask, lambda_hit, hit_threshold, sigma, lambda_hist, binedges=[edges_def, edges_pow]) is given).
     ``generated`` = [G(lr), G.srs].  Returns (loss_G, dict of parts)."""
     ground_truth = [hr, hr ** scaling_power]
     gen_lr = sum_pool(generated[0], factor)
@@ -269,8 +331,29 @@ def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Seq
         loss_gan = 0.5 * (bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), valid) +
                           bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), fake))
         tot = lambda_hr * loss_pixel + lambda_adv * loss_gan + lambda_lr * loss_lr
+        parts[k] = dict(pixel=loss_pixel, lr=loss_lr, adv=loss_gan)
+        h = heads or {}
+        if h.get("lambda_nnz", 0) > 0:                                             # esrgan.py:522-525
+            gen_nnz = softgreater(generated[k], 0, 50000).sum(1).sum(1).sum(1)
+            target = (ground_truth[k] > 0).sum(1).sum(1).sum(1).float()
+            parts[k]["nnz"] = F.mse_loss(gen_nnz, target)
+            tot = tot + h["lambda_nnz"] * parts[k]["nnz"]
+        if h.get("lambda_mask", 0) > 0:                                            # esrgan.py:526-529
+            parts[k]["mask"] = (nnz_mask(generated[k]) - nnz_mask(ground_truth[k])).abs().mean()
+            tot = tot + h["lambda_mask"] * parts[k]["mask"]
+        if h.get("lambda_hist", 0) > 0:                                            # esrgan.py:530-538
+            edges = h["binedges"][k]
+            gen_hist = diffable_histogram(generated[k][generated[k] > 0], edges, h["sigma"])
+            real_hist = diffable_histogram(ground_truth[k][ground_truth[k] > 0], edges, h["sigma"])
+            parts[k]["hist"] = kld_hist(gen_hist, real_hist, edges)
+            tot = tot + h["lambda_hist"] * parts[k]["hist"]
+        if h.get("lambda_hit", 0) > 0:                                             # esrgan.py:543-547
+            gen_hit = get_hitogram(generated[k], factor, h["hit_threshold"], h["sigma"])
+            target = get_hitogram(ground_truth[k], factor, h["hit_threshold"], h["sigma"])
+            parts[k]["hit"] = F.mse_loss(gen_hit, target)
+            tot = tot + h["lambda_hit"] * parts[k]["hit"]
         loss_G = loss_G + lambdas[k] * tot
-        parts[k] = dict(pixel=loss_pixel, lr=loss_lr, adv=loss_gan, tot=tot)
+        parts[k]["tot"] = tot
     return loss_G, parts
 
 

@@ -19,6 +19,8 @@ EXPORTS = [
     "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
+    "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
+    "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_strerror", "srk_version",
 ]
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD = 0, 1, 2
@@ -98,6 +100,17 @@ def lib():
                                       C.c_int, C.c_float, _fp, C.c_float, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
         L.srk_conv3x3_dgrad.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
+        L.srk_loss_workspace_bytes.argtypes = [C.POINTER(C.c_size_t)]
+        L.srk_sigmoid_fwd.argtypes = [_fp, _fp, C.c_long, C.c_float, C.c_float, _fp]
+        L.srk_sigmoid_bwd.argtypes = [_fp, _fp, _fp, C.c_long, C.c_float, _fp]
+        L.srk_soft_count_fwd.argtypes = [_fp, _fp, C.c_int, C.c_long, C.c_float, C.c_float, C.c_int, _fp, C.c_size_t, _fp]
+        L.srk_soft_count_bwd.argtypes = [_fp, _fp, _fp, C.c_int, C.c_long, C.c_float, C.c_float, _fp]
+        L.srk_mask_l1_fwd.argtypes = [_fp, _fp, _fp, C.c_long, C.c_float, _fp, C.c_size_t, _fp]
+        L.srk_mask_l1_bwd.argtypes = [_fp, _fp, _fp, _fp, C.c_long, C.c_float, _fp]
+        L.srk_hitogram_fwd.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, C.c_size_t, _fp]
+        L.srk_hitogram_bwd.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp]
+        L.srk_soft_hist_fwd.argtypes = [_fp, C.c_long, _fp, _fp, C.c_int, C.c_float, C.c_int, _fp, _fp, C.c_size_t, _fp]
+        L.srk_soft_hist_bwd.argtypes = [_fp, C.c_long, _fp, _fp, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp]
         _lib = L
     return _lib
 
@@ -282,6 +295,12 @@ def conv3x3_dgrad_flat(dy: "View", w, dx: "View", *, N, H, W, Cin, Cout, stride=
     ws = _workspace(workspace_bytes(OP_CONV_DGRAD, N, H, W, Cin, Cout), w.device)
     check(lib().srk_conv3x3_dgrad(dy.t.data_ptr(), dy.ldc, dy.coff, Cout, w.data_ptr(), dx.t.data_ptr(), dx.ldc, dx.coff, Cin,
                                   N, H, W, stride, ps, 0, ws.data_ptr(), ws.numel(), stream_ptr()), "srk_conv3x3_dgrad")
+
+
+def loss_workspace(device) -> torch.Tensor:
+    n = C.c_size_t(0)
+    check(lib().srk_loss_workspace_bytes(C.byref(n)), "srk_loss_workspace_bytes")
+    return _workspace(n.value, device)
 
 
 def packed_floats(K: int, M: int) -> int:

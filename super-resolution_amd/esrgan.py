@@ -34,12 +34,14 @@ DEFAULTS = dict(
     save_info=None, checkpoint_interval=500, n_checkpoints=-1, n_batches=-1, d_threshold=0.001, d_channels=[16, 32, 32, 64],
     E_thres=None, set_seed=-1, drop_rate=0, res_scale=0.1, lambda_reg=0.01, update_d=1, update_g=1, conditional=False,
     wasserstein=-1, second_discr_reset_interval=0, uniform_init=False, use_transposed_conv=False,
-    fully_transposed_conv=False, num_final_res_blocks=0, synthetic_batches=100,
+    fully_transposed_conv=False, num_final_res_blocks=0, synthetic_batches=100, hit_threshold=0.5, sigma=500, bins=10,
+    batchwise_hist=False,
 )
-UNSUPPORTED_POSITIVE = ("lambda_hist", "lambda_wasser", "lambda_nnz", "lambda_mask", "lambda_hit", "drop_rate",
-                        "second_discr_reset_interval")
+UNSUPPORTED_POSITIVE = ("lambda_wasser", "drop_rate", "second_discr_reset_interval")
+# the reference's loss_dict keys, in its order (esrgan.py:355-356)
 LOSS_KEYS = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
-             'pixel_loss_pow', 'lr_loss', 'lr_loss_pow']
+             'pixel_loss_pow', 'lr_loss', 'lr_loss_pow', 'hist_loss', 'hist_loss_pow', 'nnz_loss', 'nnz_loss_pow', 'mask_loss',
+             'mask_loss_pow', 'wasser_loss', 'wasser_loss_pow', 'hit_loss', 'hit_loss_pow', 'wasser_dist', 'wasser_dist_pow']
 
 
 def _str2bool(v):
@@ -107,10 +109,31 @@ def _check_supported(opt):
         raise NotImplementedError("transposed-conv upsampling branches are not implemented")
 
 
+def _set_binedges(st, opt, nnz, info):
+    """esrgan.py:440-456: bin edges of the energy histogram from the warm-up batches' non-zero pixels: cut at the value
+    below which 90 % of them lie, k-means cluster centres (sklearn, random_state=0) as bin centres.  Host-side, once."""
+    from sklearn.cluster import KMeans
+    nnz = np.array(nnz)
+    for k in range(2):
+        if st.lambdas[k] > 0:
+            p = [1, opt.scaling_power][k]
+            c, b = np.histogram(nnz ** p, 100)
+            e_max = b[(np.cumsum(c) > len(nnz ** p) * .9).argmax()]
+            sorted_nnz = np.sort(nnz)
+            sorted_nnz = sorted_nnz[sorted_nnz <= e_max]
+            k_mean = KMeans(n_clusters=opt.bins, random_state=0).fit(sorted_nnz.reshape(-1, 1))
+            centers = np.sort(k_mean.cluster_centers_.flatten())
+            edges = np.array([0, *(np.diff(centers) / 2 + centers[:-1]), e_max])
+            info['binedges%i' % k] = list(edges)
+            st.set_hist_binedges(k, edges)
+
+
 def train(opt, **kwargs):
     """Runs the training loop; returns the ``info`` dict that is also written to ``<model_path>/<name_>info.json``.
     kwargs: ``gpu`` (device index, esrgan.py:156), ``dataset`` (a torch Dataset yielding {"lr","hr"}; default synthetic)."""
     _check_supported(opt)
+    if opt.lambda_hist > 0:
+        assert opt.warmup_batches > 0, "if distribution learning is enabled, warmup_batches needs to be greater than 0."   # esrgan.py:159-160
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", kwargs.get("gpu", 0)))
@@ -143,7 +166,9 @@ def train(opt, **kwargs):
                         d_channels=tuple(opt.d_channels), lambdas=(opt.lambda_pix, opt.lambda_pow), lambda_hr=opt.lambda_hr,
                         lambda_adv=opt.lambda_adv, lambda_lr=opt.lambda_lr, lambda_reg=opt.lambda_reg, d_threshold=opt.d_threshold,
                         scaling_power=opt.scaling_power, multiplier=opt.pixel_multiplier, hr_shape=(opt.hr_height, opt.hr_width),
-                        num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init)
+                        num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init, lambda_nnz=opt.lambda_nnz,
+                        lambda_mask=opt.lambda_mask, lambda_hit=opt.lambda_hit, lambda_hist=opt.lambda_hist,
+                        hit_threshold=opt.hit_threshold, sigma=opt.sigma)
     if opt.E_thres:
         st.generator.thres = opt.E_thres
     load_chk = bool(opt.load_checkpoint)
@@ -174,6 +199,13 @@ def train(opt, **kwargs):
     loader = torch.utils.data.DataLoader(dataset, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler, drop_last=(world > 1))
 
     loss_dict = info.get("loss") or {k: [] for k in LOSS_KEYS}
+    for k in LOSS_KEYS:                      # info.json written before the optional heads existed
+        loss_dict.setdefault(k, [])
+    nnz = []                                 # non-zero HR pixel values seen during warm-up (esrgan.py:434-437)
+    if opt.lambda_hist > 0 and load_chk and "binedges0" in info:
+        for k in range(2):
+            if "binedges%i" % k in info:
+                st.set_hist_binedges(k, np.array(info["binedges%i" % k]))
     batches_trained = int(info.get("batches_done", 0))
     start_epoch = int(info.get("epochs", 0))
     n_batches = math.inf if opt.n_batches == -1 else opt.n_batches
@@ -204,8 +236,15 @@ def train(opt, **kwargs):
             batches_done += 1
             imgs_lr = imgs["lr"].to(device).float()
             imgs_hr = imgs["hr"].to(device).float()
-            warm = (not load_chk) and (batches_done - batches_trained < opt.warmup_batches)
+            in_warm_branch = (not load_chk) or opt.lambda_hist > 0                      # esrgan.py:417
+            warm = in_warm_branch and (batches_done - batches_trained < opt.warmup_batches)
+            if in_warm_branch and opt.lambda_hist > 0 and nnz is not None and batches_done - batches_trained == opt.warmup_batches:
+                _set_binedges(st, opt, nnz, info)                                       # esrgan.py:440-456
+                nnz = None
             if warm:
+                if opt.lambda_hist > 0:
+                    v = imgs_hr.reshape(-1)
+                    nnz.extend(list(v[v > 0].cpu().numpy()))            # float32 items, like esrgan.py:436-437
                 if opt.learn_warmup:
                     out = st.warmup_step(imgs_lr, imgs_hr)
                     if batches_done % opt.report_freq == 0:
@@ -227,7 +266,9 @@ def train(opt, **kwargs):
                     loss_dict[k].append(vals[k])
                 if rank == 0:
                     print("[Batch %d] [D def: %f, pow: %f] [G loss: %f [def: %f, pow: %f], adv: %f, adv pow: %f, pixel: %f, "
-                          "pixel pow: %f, lr pixel: %f, lr pixel pow: %f]" % ((batches_done,) + tuple(vals[k] for k in LOSS_KEYS)))
+                          "pixel pow: %f, lr pixel: %f, lr pixel pow: %f, hist: %f, hist pow: %f, nnz: %f, nnz pow: %f, mask: %f, "
+                          "mask pow: %f, wasser: %f, wasser pow: %f, hit: %f, hit pow: %f, wasserdist: %f, wasserdist pow: %f]"
+                          % ((batches_done,) + tuple(vals[k] for k in LOSS_KEYS)))
             if opt.n_checkpoints == -1 and opt.checkpoint_interval > 0 and batches_done % opt.checkpoint_interval == 0 and batches_done > 0:
                 save_weights(epoch)
             if batches_done + 1 >= total_batches:

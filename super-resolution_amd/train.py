@@ -17,7 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import models
+from . import losses, models
 
 EPS = 1e-7   # esrgan.py:319
 
@@ -45,8 +45,12 @@ class Stepper:
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
                  exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
-                 uniform_init=False):
+                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0):
         self.workload = workload
+        # optional physics heads of the G phase (esrgan.py:522-547); the histogram head needs set_hist_binedges() first
+        self.lambda_nnz, self.lambda_mask, self.lambda_hit, self.lambda_hist = lambda_nnz, lambda_mask, lambda_hit, lambda_hist
+        self.hit_threshold, self.sigma = hit_threshold, sigma
+        self.histograms, self.criterion_hist = {}, {}
         self.device = device
         self.distributed = distributed
         self.exact_dp = exact_dp and distributed
@@ -65,6 +69,7 @@ class Stepper:
                                             lr=lr_g if lr_g > 0 else lr, betas=betas, weight_decay=weight_decay, fused=True)
         self.criterion_pixel = nn.L1Loss()
         self.criterion_GAN = nn.BCEWithLogitsLoss()
+        self.mse = nn.MSELoss()
         self.pool = models.SumPool2d(factor)
         self.discriminators, self.optimizer_D = {}, {}
         if workload == "gan":
@@ -78,6 +83,11 @@ class Stepper:
         self.last = {}
 
     # ------------------------------------------------------------------ helpers
+    def set_hist_binedges(self, k, binedges):
+        """esrgan.py:454-455: bin edges of the energy histogram of view k (0 = def, 1 = pow)."""
+        self.histograms[k] = losses.DiffableHistogram(binedges, sigma=self.sigma).to(self.device)
+        self.criterion_hist[k] = losses.KLD_hist(torch.as_tensor(binedges)).to(self.device)
+
     def _gmean(self, t):
         """Batch statistic that the reference takes over the whole batch: mean over ranks of the local value."""
         return _AllReduceMean.apply(t) if self.exact_dp else t
@@ -108,12 +118,18 @@ class Stepper:
         d = out.get("d_loss", {})
 
         def g(k, name):
-            return parts[k][name].reshape(()) if k in parts else z
+            return parts[k][name].reshape(()) if k in parts and name in parts[k] else z
         vec = torch.stack([d.get(0, z).reshape(()), d.get(1, z).reshape(()), out["g_loss"].reshape(()), g(0, "tot"), g(1, "tot"),
-                           g(0, "adv"), g(1, "adv"), g(0, "pixel"), g(1, "pixel"), g(0, "lr"), g(1, "lr")]).tolist()
+                           g(0, "adv"), g(1, "adv"), g(0, "pixel"), g(1, "pixel"), g(0, "lr"), g(1, "lr"),
+                           g(0, "hist"), g(1, "hist"), g(0, "nnz"), g(1, "nnz"), g(0, "mask"), g(1, "mask"),
+                           g(0, "hit"), g(1, "hit")]).tolist()
         names = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
-                 'pixel_loss_pow', 'lr_loss', 'lr_loss_pow']
-        return dict(zip(names, vec))
+                 'pixel_loss_pow', 'lr_loss', 'lr_loss_pow', 'hist_loss', 'hist_loss_pow', 'nnz_loss', 'nnz_loss_pow',
+                 'mask_loss', 'mask_loss_pow', 'hit_loss', 'hit_loss_pow']
+        out_d = dict(zip(names, vec))
+        for name in ('wasser_loss', 'wasser_loss_pow', 'wasser_dist', 'wasser_dist_pow'):   # heads this build does not implement
+            out_d[name] = 0.0
+        return out_d
 
     # ------------------------------------------------------------------ warm-up iteration
     def warmup_step(self, imgs_lr, imgs_hr):
@@ -157,8 +173,33 @@ class Stepper:
             loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
                              self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
             tot = self.lambda_hr * loss_pixel + self.lambda_adv * loss_GAN + self.lambda_lr * loss_lr_pixel
+            parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach())
+            # optional physics heads: one fused HIP pass each (csrc/srk_loss.hip) instead of 3-6 HR-sized ATen ops.
+            # Under data parallelism these are per-rank means of per-rank batches (like the reference under DDP would be).
+            if self.lambda_nnz > 0:                                                    # esrgan.py:522-525
+                loss_nnz = self.mse(losses.soft_count(generated[k], 0.0, 50000.0), losses.hard_count(ground_truth[k], 0.0))
+                tot = tot + self.lambda_nnz * loss_nnz
+                parts[k]["nnz"] = loss_nnz.detach()
+            if self.lambda_mask > 0:                                                   # esrgan.py:526-529
+                loss_mask = losses.mask_l1(generated[k], ground_truth[k])
+                tot = tot + self.lambda_mask * loss_mask
+                parts[k]["mask"] = loss_mask.detach()
+            if self.lambda_hist > 0:                                                   # esrgan.py:530-538
+                if k not in self.histograms:
+                    raise RuntimeError("lambda_hist > 0 needs set_hist_binedges(k, edges) first (esrgan.py:441-456)")
+                gen_hist = self.histograms[k].forward_positive(generated[k])
+                real_hist = self.histograms[k].forward_positive(ground_truth[k])
+                loss_hist = self.criterion_hist[k](gen_hist, real_hist)
+                tot = tot + self.lambda_hist * loss_hist
+                parts[k]["hist"] = loss_hist.detach()
+            if self.lambda_hit > 0:                                                    # esrgan.py:543-547
+                gen_hit = losses.get_hitogram(generated[k], self.factor, self.hit_threshold, self.sigma)
+                target = losses.get_hitogram(ground_truth[k], self.factor, self.hit_threshold, self.sigma)
+                loss_hit = self.mse(gen_hit, target)
+                tot = tot + self.lambda_hit * loss_hit
+                parts[k]["hit"] = loss_hit.detach()
             loss_G = loss_G + self.lambdas[k] * tot
-            parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach(), tot=tot.detach())
+            parts[k]["tot"] = tot.detach()
         return loss_G, generated, ground_truth, parts
 
     def d_phase_loss(self, k, gt, gen_detached, epsilon=None):

@@ -1,0 +1,135 @@
+"""GPU: the fused loss-head kernels (csrc/srk_loss.hip via super-resolution_amd.losses) against
+  * the reference-generated fixture tests/golden/G11_loss_heads.npz (values and gradients), and
+  * the CPU oracle on larger seeded inputs, ragged sizes and every supported factor,
+  * size-independent properties at the headline size (32 x 1 x 256 x 256): run-to-run determinism (bit-exact) and
+    consistency between the fused forms and the stand-alone elementwise functions.
+Tolerances: 1e-5 relative to the fixture's max-abs for values (fp32 sums of up to 2M terms in a different order),
+2e-5 for gradients (expf vs torch's sigmoid differ in the last ulps, amplified by sigma)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import esrgan_oracle as O  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+VT, GT = 1e-5, 2e-5
+
+
+@pytest.fixture(scope="module")
+def LS():
+    return importlib.import_module("super-resolution_amd").losses
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double(); b = torch.as_tensor(b).detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_heads_match_reference_fixture(LS, golden_dir):
+    d = np.load(os.path.join(golden_dir, "G11_loss_heads.npz"))
+    gt = torch.from_numpy(d["gt"]).cuda(); f = int(d["factor"])
+
+    def leaf():
+        return torch.from_numpy(d["gen"]).cuda().requires_grad_(True)
+    for name, fn in (("softgreater", lambda t: LS.softgreater(t, 0.2, 30, 0.05)), ("nnz_mask", lambda t: LS.nnz_mask(t, 7.0))):
+        x = leaf(); y = fn(x)
+        gx, = torch.autograd.grad((y * torch.from_numpy(d[name + ".w"]).cuda()).sum(), x)
+        assert rel(y, d[name + ".y"]) < VT and rel(gx, d[name + ".dx"]) < GT
+    for tag, sig in (("nnz", 50000.0), ("nnz_soft", 3.0)):
+        x = leaf()
+        cnt = LS.soft_count(x, 0.0, sig)
+        tgt = LS.hard_count(gt, 0.0)
+        loss = torch.nn.functional.mse_loss(cnt, tgt)
+        gx, = torch.autograd.grad(loss, x)
+        assert torch.equal(tgt.cpu(), torch.from_numpy(d[tag + ".target"]))
+        assert rel(cnt, d[tag + ".count"]) < VT and rel(loss, d[tag + ".loss"]) < 1e-4 and rel(gx, d[tag + ".dx"]) < 1e-4
+    for tag, sig in (("mask", 5e4), ("mask_soft", 2.0)):
+        x = leaf()
+        loss = LS.mask_l1(x, gt, sig)
+        gx, = torch.autograd.grad(loss, x)
+        assert rel(loss, d[tag + ".loss"]) < VT
+        assert (gx.cpu() - torch.from_numpy(d[tag + ".dx"])).abs().max().item() <= GT * max(np.abs(d[tag + ".dx"]).max(), 1e-12) + 1e-12
+    for tag, thr, sig in (("hit", 0.5, 500.0), ("hit_soft", 0.5, 2.0), ("hit_mean", 0.5, -1.0)):
+        x = leaf()
+        gh, th = LS.get_hitogram(x, f, thr, sig), LS.get_hitogram(gt, f, thr, sig)
+        loss = torch.nn.functional.mse_loss(gh, th)
+        gx, = torch.autograd.grad(loss, x)
+        assert rel(gh, d[tag + ".gen"]) < VT and rel(th, d[tag + ".target"]) < VT
+        assert rel(gx, d[tag + ".dx"]) < 2e-3          # d(mse of two nearly equal 4x4 means): cancellation in (gen - target)
+    for tag, sig in (("hist", 500.0), ("hist_soft", 4.0)):
+        x = leaf()
+        hist = LS.DiffableHistogram(d["hist.edges"], sigma=sig).to("cuda")
+        crit = LS.KLD_hist(torch.from_numpy(d["hist.edges"])).to("cuda")
+        gen_hist = hist.forward_positive(x)
+        real_hist = hist.forward_positive(gt)
+        assert rel(gen_hist, d[tag + ".gen"]) < VT and rel(real_hist, d[tag + ".real"]) < VT
+        loss = crit(gen_hist, real_hist)
+        gx, = torch.autograd.grad(loss, x)
+        assert rel(loss, d[tag + ".loss"]) < 1e-4 and rel(gx, d[tag + ".dx"]) < 1e-4
+        assert rel(hist(x.detach()), d[tag + ".all"]) < VT
+        # the reference's calling convention (gather first) gives the same numbers
+        assert rel(hist(x.detach()[x.detach() > 0]), d[tag + ".gen"]) < VT
+
+
+@pytest.mark.parametrize("B,C,H,W,f", [(4, 1, 64, 64, 2), (3, 2, 40, 24, 4), (2, 1, 80, 80, 8), (5, 3, 7, 9, 1), (1, 1, 512, 300, 4)])
+def test_heads_vs_oracle_shapes(LS, B, C, H, W, f):
+    _, gt = O.jet_images(B, C, H, W, 100 + H, 1)
+    g = torch.Generator().manual_seed(H * W)
+    gen = (gt + 0.2 * torch.randn(gt.shape, generator=g)).clamp_min(0)
+    xo = gen.clone().requires_grad_(True)
+    xg = gen.cuda().requires_grad_(True)
+    gtg = gt.cuda()
+    edges = np.array([0.0, 0.7, 1.9, 3.2, 5.5, 9.0])
+    heads = dict(lambda_nnz=1.0, lambda_mask=1.0, lambda_hit=1.0, hit_threshold=0.5, sigma=3.0, lambda_hist=1.0, binedges=[edges, edges])
+    # oracle composition (esrgan.py:522-547), soft sigmas so that every head has a non-trivial gradient
+    cnt_o = O.softgreater(xo, 0, 5.0).sum(1).sum(1).sum(1)
+    lo = torch.nn.functional.mse_loss(cnt_o, (gt > 0).sum(1).sum(1).sum(1).float()) * 1e-4
+    lo = lo + (O.nnz_mask(xo, 2.0) - O.nnz_mask(gt, 2.0)).abs().mean()
+    lo = lo + torch.nn.functional.mse_loss(O.get_hitogram(xo, f, 0.5, 3.0), O.get_hitogram(gt, f, 0.5, 3.0)) * 100
+    lo = lo + O.kld_hist(O.diffable_histogram(xo[xo > 0], edges, 3.0), O.diffable_histogram(gt[gt > 0], edges, 3.0), edges)
+    go, = torch.autograd.grad(lo, xo)
+    cnt = LS.soft_count(xg, 0.0, 5.0)
+    lg = torch.nn.functional.mse_loss(cnt, LS.hard_count(gtg)) * 1e-4
+    lg = lg + LS.mask_l1(xg, gtg, 2.0)
+    lg = lg + torch.nn.functional.mse_loss(LS.get_hitogram(xg, f, 0.5, 3.0), LS.get_hitogram(gtg, f, 0.5, 3.0)) * 100
+    hist = LS.DiffableHistogram(edges, sigma=3.0).to("cuda")
+    lg = lg + LS.KLD_hist(torch.from_numpy(edges)).to("cuda")(hist.forward_positive(xg), hist.forward_positive(gtg))
+    gg, = torch.autograd.grad(lg, xg)
+    assert rel(cnt, cnt_o) < VT
+    assert abs(lg.item() - lo.item()) <= 1e-4 * abs(lo.item())
+    assert rel(gg, go) < 2e-4
+    assert heads  # (documented above; the dict form is exercised through train.Stepper in test_train_gpu.py)
+
+
+def test_heads_full_size_properties(LS):
+    """Headline size: bit-exact determinism of every reduction, and fused == stand-alone composition."""
+    _, gt = O.jet_images(32, 1, 256, 256, 5, 1)
+    gen = (gt + 0.1 * torch.randn(gt.shape, generator=torch.Generator().manual_seed(1))).clamp_min(0).cuda()
+    gt = gt.cuda()
+    edges = np.linspace(0.0, 10.0, 11)
+    hist = LS.DiffableHistogram(edges, sigma=500.0).to("cuda")
+    runs = []
+    for _ in range(2):
+        runs.append([LS.soft_count(gen, 0.0, 50000.0), LS.mask_l1(gen, gt, 5e4), LS.get_hitogram(gen, 4, 0.5, 500.0), hist.forward_positive(gen)])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    cnt, ml1, hit, hh = runs[0]
+    assert rel(cnt, LS.softgreater(gen, 0, 50000.0).sum((1, 2, 3))) < 1e-5
+    assert rel(ml1, (LS.nnz_mask(gen) - LS.nnz_mask(gt)).abs().mean()) < 1e-5
+    blocks = torch.sigmoid(500.0 * (gen.view(32, 1, 64, 4, 64, 4) - 0.5)).mean((0, 1, 2, 4))
+    assert rel(hit, blocks) < 1e-5
+    assert rel(hh.sum(), torch.tensor(float((gen > 0).sum().item()))) < 0.2      # nearly every positive entry falls in one of the 10 bins
+
+
+def test_heads_fail_loudly_on_cpu_and_bad_args(LS):
+    with pytest.raises(RuntimeError):
+        LS.soft_count(torch.zeros(2, 1, 4, 4))
+    with pytest.raises(RuntimeError):
+        LS.get_hitogram(torch.zeros(2, 1, 6, 6, device="cuda"), 4)       # 6 % 4 != 0: torch.cat of ragged splits raises in the reference too
+    with pytest.raises(RuntimeError):
+        LS.get_hitogram(torch.zeros(2, 1, 6, 6, device="cuda"), 3)       # unsupported factor

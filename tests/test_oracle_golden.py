@@ -113,3 +113,49 @@ def test_G7_discriminator(golden_dir):
     for shp in [(1, 80, 80), (1, 75, 75), (1, 256, 256)]:
         o = O.discriminator_output_shape(shp)
         assert o == (1, -(-shp[1] // 16), -(-shp[2] // 16))
+
+
+def test_G11_loss_heads(golden_dir):
+    """The oracle's restatement of softgreater / nnz_mask / get_hitogram / DiffableHistogram / KLD_hist and of the way
+    esrgan.py:522-547 composes them, against values and gradients produced by the reference's own functions
+    (tools/make_golden_heads.py)."""
+    d = np.load(os.path.join(golden_dir, "G11_loss_heads.npz"))
+    gt = torch.from_numpy(d["gt"]); f = int(d["factor"])
+
+    def leaf():
+        return torch.from_numpy(d["gen"]).clone().requires_grad_(True)
+    for name, fn in (("softgreater", lambda t: O.softgreater(t, 0.2, 30, 0.05)), ("nnz_mask", lambda t: O.nnz_mask(t, 7.0))):
+        x = leaf(); y = fn(x)
+        gx, = torch.autograd.grad((y * torch.from_numpy(d[name + ".w"])).sum(), x)
+        assert close(y.detach(), d[name + ".y"]) and close(gx, d[name + ".dx"])
+    for tag, sig in (("nnz", 50000.0), ("nnz_soft", 3.0)):
+        x = leaf()
+        cnt = O.softgreater(x, 0, sig).sum(1).sum(1).sum(1)
+        tgt = (gt > 0).sum(1).sum(1).sum(1).float()
+        loss = torch.nn.functional.mse_loss(cnt, tgt)
+        gx, = torch.autograd.grad(loss, x)
+        assert close(cnt.detach(), d[tag + ".count"]) and close(tgt, d[tag + ".target"]) and close(loss.detach(), d[tag + ".loss"]) and close(gx, d[tag + ".dx"])
+    for tag, sig in (("mask", 5e4), ("mask_soft", 2.0)):
+        x = leaf()
+        loss = (O.nnz_mask(x, sig) - O.nnz_mask(gt, sig)).abs().mean()
+        gx, = torch.autograd.grad(loss, x)
+        assert close(loss.detach(), d[tag + ".loss"], 1e-6) and close(gx, d[tag + ".dx"], 1e-6)
+    for tag, thr, sig in (("hit", 0.5, 500.0), ("hit_soft", 0.5, 2.0), ("hit_mean", 0.5, -1.0)):
+        x = leaf()
+        gh, th = O.get_hitogram(x, f, thr, sig), O.get_hitogram(gt, f, thr, sig)
+        loss = torch.nn.functional.mse_loss(gh, th)
+        gx, = torch.autograd.grad(loss, x)
+        assert close(gh.detach(), d[tag + ".gen"], 1e-6) and close(th, d[tag + ".target"], 1e-6)
+        assert abs(loss.item() - float(d[tag + ".loss"])) <= 1e-5 * float(d[tag + ".loss"])
+        assert (gx - torch.from_numpy(d[tag + ".dx"])).abs().max().item() <= 1e-5 * np.abs(d[tag + ".dx"]).max()
+    edges = O.hist_binedges(d["hist.nnz"], 6, 1.0)
+    assert np.allclose(edges, d["hist.edges"], rtol=1e-6, atol=0)
+    for tag, sig in (("hist", 500.0), ("hist_soft", 4.0)):
+        x = leaf()
+        gen_hist = O.diffable_histogram(x[x > 0], d["hist.edges"], sig)
+        real_hist = O.diffable_histogram(gt[gt > 0], d["hist.edges"], sig)
+        loss = O.kld_hist(gen_hist, real_hist, d["hist.edges"])
+        gx, = torch.autograd.grad(loss, x)
+        assert close(gen_hist.detach(), d[tag + ".gen"]) and close(real_hist, d[tag + ".real"])
+        assert close(loss.detach(), d[tag + ".loss"]) and (gx - torch.from_numpy(d[tag + ".dx"])).abs().max().item() <= 1e-5 * np.abs(d[tag + ".dx"]).max()
+        assert close(O.diffable_histogram(x.detach(), d["hist.edges"], sig), d[tag + ".all"])

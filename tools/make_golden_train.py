@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/G8_train_trajectory.npz by DRIVING the reference's own ``esrgan.train()`` (build container
+"""Generate tests/golden/G8_train_trajectory.npz (and, with ``--heads``, G12_train_heads_trajectory.npz) by DRIVING the reference's own ``esrgan.train()`` (build container
 only).  The reference loop runs unmodified on CPU; three inert accommodations, all off the hot path:
   1. empty stand-in modules for packages that are absent here and only needed by plotting / dataset I/O
      (torchvision, h5py, energyflow), placed in sys.modules before the import;
@@ -55,7 +55,10 @@ import matplotlib  # noqa: E402
 matplotlib.use("Agg")
 import esrgan as ref  # noqa: E402  (the reference, imported read-only)
 
+HEADS = "--heads" in sys.argv      # second fixture: the optional physics loss heads switched on (esrgan.py:522-547)
 CFG = dict(hr=16, factor=2, R=1, batch=4, n_batches=5, warmup=2, seed=7, n_items=16)
+HEAD_FLAGS = ["--lambda_nnz", "1e-5", "--lambda_mask", "0.5", "--lambda_hit", "20", "--lambda_hist", "0.05", "--bins", "4",
+              "--sigma", "5", "--hit_threshold", "0.5"]
 
 # ---- (3) dataset, closed-form weights, epsilon recorder
 lr_all, hr_all = O.jet_images(CFG["n_items"], 1, CFG["hr"], CFG["hr"], 99, CFG["factor"])
@@ -109,7 +112,7 @@ sys.argv = ["esrgan.py", "--n_epochs", "10", "--batch_size", str(CFG["batch"]), 
             "--hr_height", str(CFG["hr"]), "--hr_width", str(CFG["hr"]), "--residual_blocks", str(CFG["R"]),
             "--warmup_batches", str(CFG["warmup"]), "--n_batches", str(CFG["n_batches"]), "--report_freq", "1",
             "--set_seed", str(CFG["seed"]), "--root", tmp, "--model_path", "m", "--sample_interval", "-1",
-            "--name", "g8", "--res_scale", "0.1"]
+            "--name", "g8", "--res_scale", "0.1"] + (HEAD_FLAGS if HEADS else [])
 opt = ref.get_parser()
 opt.save = False
 opt.save_info = True
@@ -125,10 +128,15 @@ arrs = dict(cfg=np.array([CFG["hr"], CFG["factor"], CFG["R"], CFG["batch"], CFG[
             lr=lr_all[order.reshape(-1)].reshape(order.shape[0], CFG["batch"], 1, CFG["hr"] // CFG["factor"], CFG["hr"] // CFG["factor"]),
             hr=hr_all[order.reshape(-1)].reshape(order.shape[0], CFG["batch"], 1, CFG["hr"], CFG["hr"]),
             eps=torch.stack(eps_log) if eps_log else torch.zeros(0))
+if HEADS:
+    arrs["binedges0"] = np.array(info["binedges0"], dtype=np.float64)
+    arrs["binedges1"] = np.array(info["binedges1"], dtype=np.float64)
+    arrs["head_flags"] = np.array([float(x) for x in HEAD_FLAGS[1::2]], dtype=np.float64)   # nnz, mask, hit, hist, bins, sigma, hit_threshold
 for k in ["g_loss", "d_loss_def", "d_loss_pow", "def_loss", "pow_loss", "adv_loss", "adv_loss_pow", "pixel_loss", "pixel_loss_pow",
-          "lr_loss", "lr_loss_pow"]:
+          "lr_loss", "lr_loss_pow"] + (["hist_loss", "hist_loss_pow", "nnz_loss", "nnz_loss_pow", "mask_loss", "mask_loss_pow",
+                                       "hit_loss", "hit_loss_pow"] if HEADS else []):
     arrs["loss." + k] = np.array(loss[k], dtype=np.float64)
     print(k, loss[k])
-out = os.path.join(ROOT, "tests", "golden", "G8_train_trajectory.npz")
+out = os.path.join(ROOT, "tests", "golden", "G12_train_heads_trajectory.npz" if HEADS else "G8_train_trajectory.npz")
 np.savez_compressed(out, **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in arrs.items()})
 print("wrote", out, os.path.getsize(out))
