@@ -237,6 +237,25 @@ def discriminator_forward(sd, img: Tensor, channels=(16, 32, 32, 64)) -> Tensor:
     return conv3x3(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], 1)
 
 
+def conditional_discriminator_forward(sd, img: Tensor, cond: Tensor, channels=(32, 64, 128, 256), num_upsample=3) -> Tensor:
+    """Conditional_Discriminator.forward (models.py:189-223): the HR image goes through ``num_upsample`` stride-(1,2)
+    blocks (model_hr), the LR condition through as many stride-(1,1) blocks (model_c); their outputs are concatenated
+    on the channel axis and finished by the remaining blocks + the 1-channel conv (endmodel)."""
+    def block(x, prefix, idx, s2):
+        x = lrelu(conv3x3(x, sd[f"{prefix}.{idx}.weight"], sd[f"{prefix}.{idx}.bias"], 1), D_SLOPE)
+        return lrelu(conv3x3(x, sd[f"{prefix}.{idx+2}.weight"], sd[f"{prefix}.{idx+2}.bias"], s2), D_SLOPE)
+    h, c = img, cond
+    for i in range(min(num_upsample, len(channels))):
+        h = block(h, "model_hr", 4 * i, 2)
+        c = block(c, "model_c", 4 * i, 1)
+    x = torch.cat([h, c], 1)
+    idx = 0
+    for i in range(num_upsample, len(channels)):
+        x = block(x, "endmodel", idx, 2)
+        idx += 4
+    return conv3x3(x, sd[f"endmodel.{idx}.weight"], sd[f"endmodel.{idx}.bias"], 1)
+
+
 # --------------------------------------------------------------------------- train-step losses
 EPS = 1e-7  # esrgan.py:319
 
@@ -309,7 +328,7 @@ def hist_binedges(nnz, bins: int, power: float = 1.0):
 def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Sequence[dict],
                  factor: int, scaling_power: float = 1.0, lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1,
-                 d_channels=(16, 32, 32, 64), heads: Optional[dict] = None):
+                 d_channels=(16, 32, 32, 64), heads: Optional[dict] = None, cond_num_upsample: Optional[int] = None):
     """esrgan.py:468-552 (relativistic; hr+lr+adv terms, plus the optional heads of esrgan.py:522-547 when ``heads`` =
     dict(lambda_nnz, lambda_mask, lambda_hit, hit_threshold, sigma, lambda_hist, binedges=[edges_def, edges_pow]) is given).
     ``generated`` = [G(lr), G.srs].  Returns (loss_G, dict of parts)."""
@@ -324,8 +343,12 @@ def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Seq
             continue
         loss_pixel = (generated[k].mean(0)[None] - ground_truth[k].mean(0)[None]).abs().mean()
         loss_lr = (generated_lr[k] - ground_truth_lr[k]).abs().mean()
-        pred_real = discriminator_forward(d_sds[k], ground_truth[k], d_channels).detach()
-        pred_fake = discriminator_forward(d_sds[k], generated[k], d_channels)
+        if cond_num_upsample is not None:      # Conditional_Discriminator(img, lr) (esrgan.py:493-494)
+            pred_real = conditional_discriminator_forward(d_sds[k], ground_truth[k], ground_truth_lr[k], d_channels, cond_num_upsample).detach()
+            pred_fake = conditional_discriminator_forward(d_sds[k], generated[k], generated_lr[k], d_channels, cond_num_upsample)
+        else:
+            pred_real = discriminator_forward(d_sds[k], ground_truth[k], d_channels).detach()
+            pred_fake = discriminator_forward(d_sds[k], generated[k], d_channels)
         valid = torch.ones_like(pred_real)
         fake = torch.zeros_like(pred_real)
         loss_gan = 0.5 * (bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), valid) +
@@ -358,9 +381,15 @@ def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Seq
 
 
 def d_phase_loss(d_sd: dict, gt: Tensor, gen_detached: Tensor, epsilon: Optional[Tensor],
-                 lambda_reg=0.01, d_channels=(16, 32, 32, 64)):
+                 lambda_reg=0.01, d_channels=(16, 32, 32, 64), cond: Optional[Tensor] = None, num_upsample: int = 0):
     """esrgan.py:569-606 for one discriminator (relativistic + gradient penalty).
-    ``epsilon``: (B,1,1,1) interpolation factors (esrgan.py:598) or None to skip GP."""
+    ``epsilon``: (B,1,1,1) interpolation factors (esrgan.py:598) or None to skip GP.
+    ``cond`` (the LR ground truth, esrgan.py:569-570,601) selects the Conditional_Discriminator."""
+    if cond is not None:
+        def discriminator_forward(sd, x, ch):          # noqa: F811  (conditional variant, same call sites)
+            return conditional_discriminator_forward(sd, x, cond, ch, num_upsample)
+    else:
+        discriminator_forward = globals()["discriminator_forward"]
     pred_real = discriminator_forward(d_sd, gt, d_channels)
     pred_fake = discriminator_forward(d_sd, gen_detached, d_channels)
     valid = torch.ones_like(pred_real)

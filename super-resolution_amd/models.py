@@ -224,6 +224,72 @@ class Standard_Discriminator(Markovian_Discriminator):
         return self.fc(ops.to_nchw(z).reshape(img.shape[0], -1))
 
 
+def _run_preact_chain(seq, packed, z, in_slope, need_bwd):
+    """z_l = conv(lrelu(z_{l-1})) over an nn.Sequential of Conv3x3 / LeakyReLU; returns (z, pending LeakyReLU slope)."""
+    ci = 0
+    for m in seq:
+        if isinstance(m, nn.Conv2d):
+            z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope, packed.fwd[ci], packed.bwd[ci] if need_bwd else None)
+            ci += 1
+            in_slope = 1.0
+        elif isinstance(m, nn.LeakyReLU):
+            in_slope = m.negative_slope
+        else:
+            raise RuntimeError("unexpected layer in a discriminator conv chain")
+    return z, in_slope
+
+
+class Conditional_Discriminator(nn.Module):
+    """models.py:189-223: the HR image runs through ``num_upsample`` stride-(1,2) blocks (``model_hr``), the LR condition
+    through as many stride-(1,1) blocks (``model_c``); both land on the LR grid, are concatenated on the channel axis and
+    finished by ``endmodel``.  Same pre-activation NHWC chains as Markovian_Discriminator (the LeakyReLU that closes both
+    branches is applied while the first endmodel conv stages the concatenation); twice differentiable w.r.t. ``img``."""
+
+    def __init__(self, input_shape, channels=[32, 64, 128, 256], num_upsample=3):
+        super().__init__()
+        self.channels = channels
+        self.input_shape = input_shape
+        in_channels, in_height, in_width = self.input_shape
+
+        def stride2(x):
+            return int(np.ceil(x / 2))
+        patch_h, patch_w = in_height, in_width
+        hrlayers, clayers, endlayers = [], [], []
+        in_filters = in_channels
+        for i, out_filters in enumerate(self.channels):
+            if i < num_upsample:
+                hrlayers.extend(discriminator_block(in_filters, out_filters))
+                clayers.extend(discriminator_block(in_filters, out_filters, stride=(1, 1)))
+            elif i == num_upsample:
+                endlayers.extend(discriminator_block(in_filters * 2, out_filters))
+            else:
+                endlayers.extend(discriminator_block(in_filters, out_filters))
+            in_filters = out_filters
+            patch_h, patch_w = stride2(patch_h), stride2(patch_w)
+        endlayers.append(Conv3x3(out_filters, 1, kernel_size=3, stride=1, padding=1))
+        self.output_shape = (1, patch_h, patch_w)
+        self.model_hr = nn.Sequential(*hrlayers)
+        self.model_c = nn.Sequential(*clayers)
+        self.endmodel = nn.Sequential(*endlayers)
+        self._packed = None
+
+    def forward(self, img, cond):
+        seqs = (self.model_hr, self.model_c, self.endmodel)
+        convs = [[m for m in seq if isinstance(m, nn.Conv2d)] for seq in seqs]
+        if self._packed is None:
+            self._packed = [ops.PackedConvs(c) for c in convs]
+        need_bwd = torch.is_grad_enabled() and (img.requires_grad or cond.requires_grad or
+                                                any(c.weight.requires_grad for cs in convs for c in cs))
+        for pk in self._packed:
+            pk.refresh(need_bwd)
+        zh, sh = _run_preact_chain(self.model_hr, self._packed[0], ops.to_nhwc(img.float()), 1.0, need_bwd)
+        zc, sc = _run_preact_chain(self.model_c, self._packed[1], ops.to_nhwc(cond.float()), 1.0, need_bwd)
+        if sh != sc:
+            raise RuntimeError("Conditional_Discriminator: branches end in different activations")
+        z, s = _run_preact_chain(self.endmodel, self._packed[2], torch.cat([zh, zc], 3), sh, need_bwd)
+        return ops.to_nchw(z)
+
+
 class SumPool2d(nn.Module):
     """models.py:297-305: k*k * AvgPool2d(k)."""
 

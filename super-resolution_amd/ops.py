@@ -57,6 +57,9 @@ class PackedConvs:
         self.tab_b.finalize()
 
     def refresh(self, need_bwd: bool):
+        if not self.convs:
+            self.fwd, self.bwd = [], []
+            return
         sig = tuple(c.weight.data_ptr() for c in self.convs)
         if sig != self._sig:
             self._build()

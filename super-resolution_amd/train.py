@@ -45,8 +45,9 @@ class Stepper:
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
                  exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
-                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0):
+                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False):
         self.workload = workload
+        self.conditional = conditional
         # optional physics heads of the G phase (esrgan.py:522-547); the histogram head needs set_hist_binedges() first
         self.lambda_nnz, self.lambda_mask, self.lambda_hit, self.lambda_hist = lambda_nnz, lambda_mask, lambda_hit, lambda_hist
         self.hit_threshold, self.sigma = hit_threshold, sigma
@@ -75,7 +76,11 @@ class Stepper:
         if workload == "gan":
             for k in range(2):
                 if self.lambdas[k] > 0:
-                    D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
+                    if conditional:       # esrgan.py:213-219
+                        D = models.Conditional_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels),
+                                                             num_upsample=int(math.log2(factor))).to(device)
+                    else:
+                        D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     self.discriminators[k] = D
                     self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas, fused=True)
         if distributed:
@@ -202,11 +207,12 @@ class Stepper:
             parts[k]["tot"] = tot.detach()
         return loss_G, generated, ground_truth, parts
 
-    def d_phase_loss(self, k, gt, gen_detached, epsilon=None):
-        """esrgan.py:569-606 for discriminator k.  ``epsilon``: (B,1,1,1) interpolation factors or None -> drawn here."""
+    def d_phase_loss(self, k, gt, gen_detached, epsilon=None, cond=None):
+        """esrgan.py:569-606 for discriminator k.  ``epsilon``: (B,1,1,1) interpolation factors or None -> drawn here.
+        ``cond``: the LR ground truth, second argument of all three D calls (only the conditional discriminator reads it)."""
         D = self.discriminators[k]
-        pred_real = D(gt, None)
-        pred_fake = D(gen_detached, None)
+        pred_real = D(gt, cond)
+        pred_fake = D(gen_detached, cond)
         valid = torch.ones_like(pred_real)
         fake = torch.zeros_like(pred_real)
         loss_real = self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), valid)
@@ -219,7 +225,7 @@ class Stepper:
                 epsilon = torch.rand(B, 1, 1, 1, device=gt.device)
             interpolation = epsilon * gt + (1 - epsilon) * gen_detached
             interpolation.requires_grad = True
-            pred_interpolation = D(interpolation, None)
+            pred_interpolation = D(interpolation, cond)
             gradients = torch.autograd.grad(outputs=pred_interpolation, inputs=interpolation, grad_outputs=valid,
                                             create_graph=True, retain_graph=True, only_inputs=True)[0]
             gradients = gradients.view(B, -1)
@@ -239,11 +245,13 @@ class Stepper:
                 generated = [self.generator(imgs_lr), self.generator.srs]
             ground_truth = [imgs_hr, imgs_hr ** self.scaling_power]
             loss_G, parts = torch.zeros(1, device=imgs_lr.device), {}
+        ground_truth_lr = [imgs_lr, imgs_lr ** self.scaling_power]
         # ---- discriminators (esrgan.py:561-626); they see the pre-update generator output
         loss_D_tot = {}
         for k, D in (self.discriminators.items() if update_d else ()):
             self.optimizer_D[k].zero_grad(set_to_none=True)
-            loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k])
+            loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
+                                           cond=ground_truth_lr[k])
             loss_D.backward()
             self._sync_grads(D)
             gate = loss_D.detach()

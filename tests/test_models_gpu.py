@@ -158,6 +158,41 @@ def test_discriminator_golden_with_gradient_penalty(srk, golden_dir):
         assert rel(p.grad.cpu(), torch.from_numpy(d["grad." + k])) < GRAD_TOL, k
 
 
+def test_conditional_discriminator_golden(srk, golden_dir):
+    """Conditional_Discriminator (models.py:189-223) forward on (HR, LR condition), relativistic D loss + gradient penalty
+    double backward with the LR ground truth as condition (esrgan.py:569-606), against the reference-generated G13; and the
+    state_dict key contract."""
+    d = np.load(os.path.join(golden_dir, "G13_conditional_discriminator.npz"))
+    cfg = [int(v) for v in d["cfg"]]
+    ch, nu, hr = cfg[:4], cfg[4], cfg[5]
+    D = srk.Conditional_Discriminator((1, hr, hr), ch, num_upsample=nu).cuda()
+    assert list(D.state_dict().keys()) == open(os.path.join(golden_dir, "G13_state_keys.txt")).read().split()
+    _load_closed_form(D, gain=2.0)
+    assert tuple(D.output_shape) == tuple(int(v) for v in d["out_shape"])
+    lr, gt, gen, eps = [torch.from_numpy(d[k]).cuda() for k in ("lr", "gt", "gen", "eps")]
+    pred_real, pred_fake = D(gt, lr), D(gen, lr)
+    assert rel(pred_real.detach().cpu(), torch.from_numpy(d["pred_real"])) < OUT_TOL
+    assert rel(pred_fake.detach().cpu(), torch.from_numpy(d["pred_fake"])) < OUT_TOL
+    crit = torch.nn.BCEWithLogitsLoss()
+    valid = torch.ones(3, *D.output_shape, device="cuda"); fake = torch.zeros_like(valid)
+    loss_D = (crit(1e-7 + pred_real - pred_fake.mean(0, keepdim=True), valid) + crit(1e-7 + pred_fake - pred_real.mean(0, keepdim=True), fake)) / 2
+    interp = (eps * gt + (1 - eps) * gen)
+    interp.requires_grad = True
+    pi = D(interp, lr)
+    grads = torch.autograd.grad(outputs=pi, inputs=interp, grad_outputs=valid, create_graph=True, retain_graph=True, only_inputs=True)[0]
+    assert rel(grads.detach().cpu(), torch.from_numpy(d["input_grad_gp"])) < GRAD_TOL
+    gp = ((grads.view(3, -1).norm(2, dim=1) - 1) ** 2).mean() * 0.01 / 2
+    tot = loss_D + gp
+    assert abs(gp.item() - float(d["gp"])) < 1e-3 * float(d["gp"]) and abs(tot.item() - float(d["loss"])) < 1e-4
+    tot.backward()
+    for k, p in D.named_parameters():
+        assert rel(p.grad.cpu(), torch.from_numpy(d["grad." + k])) < GRAD_TOL, k
+    # the condition branch is differentiable too (the G phase feeds pool(G(lr)) as condition, esrgan.py:494)
+    c = lr.clone().requires_grad_(True)
+    D(gen, c).sum().backward()
+    assert c.grad is not None and torch.isfinite(c.grad).all() and c.grad.abs().max() > 0
+
+
 def test_discriminator_ragged_shapes(srk):
     for shp in [(1, 80, 80), (1, 75, 75), (3, 40, 24)]:
         D = srk.Markovian_Discriminator(shp, [16, 32, 32, 64]).cuda()
