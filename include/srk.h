@@ -197,6 +197,13 @@ int srk_soft_hist_fwd(const float* x, long n, const float* centers, const float*
 int srk_soft_hist_bwd(const float* x, long n, const float* centers, const float* delta, int K, float sigma, int positive_only,
                       const float* gout, float* dx, void* stream);
 
+/* Sparse jet decode: the batched form of datasets.py:136-145 `extract` (+ ThresholdImageCutter, datasets.py:170-175).
+ * rows [B][row_stride] fp32 = interleaved (pos_i, E_i) pairs, L per event, zero-padded; out [B][etaBins][phiBins]
+ * (= NCHW with one channel): out[b][pos % etaBins][pos // etaBins] += E in list order up to the first E == 0; pixels
+ * <= threshold are zeroed (threshold < 0: no cut).  One workgroup per event, bit-identical to the sequential loop. */
+int srk_jet_extract(const float* rows, int B, int L, int row_stride, int etaBins, int phiBins, float threshold, float* out,
+                    void* stream);
+
 /* Flat, self-contained entry points on CANONICAL OIHW fp32 weights (SURVEY.md section 8(b)'s signatures): the weights are
  * packed into the caller's workspace on `stream`, then the fused kernel above runs.  For callers that do not keep
  * packed weights alive (one conv at a time from another framework); the training engine uses srk_conv3x3 directly.

@@ -28,6 +28,8 @@ Reference citations (file:line in /root/reference):
   utils.py:90-113   KLD_hist                  -> kld_hist
   esrgan.py:434-456 bin edges of the energy histogram -> hist_binedges
   esrgan.py:522-547 optional loss heads       -> g_phase_loss(heads=...)
+  models.py:189-223 Conditional_Discriminator -> conditional_discriminator_forward
+  datasets.py:136-145,170-201,232-249 extract / cutters / SparseJetDataset item -> extract, *_cutter, sparse_jet_item
 """
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -254,6 +256,45 @@ def conditional_discriminator_forward(sd, img: Tensor, cond: Tensor, channels=(3
         x = block(x, "endmodel", idx, 2)
         idx += 4
     return conv3x3(x, sd[f"endmodel.{idx}.weight"], sd[f"endmodel.{idx}.bias"], 1)
+
+
+# --------------------------------------------------------------------------- jet data decode
+def extract(data: Tensor, etaBins: int, phiBins: int, channels: int = 1) -> Tensor:
+    """datasets.py:136-145: data [2, L] (positions, energies) -> [channels, etaBins, phiBins]; sequential accumulate, stop
+    after the first zero energy."""
+    rec = torch.zeros((channels, etaBins, phiBins))
+    for i in range(data.shape[1]):
+        pos = data[0, i]
+        phi = int(pos // etaBins)
+        eta = int(pos % etaBins)
+        rec[0, eta, phi] += data[1, i]
+        if data[1, i] == 0:
+            break
+    return rec.float()
+
+
+def threshold_cutter(x: Tensor, thres) -> Tensor:
+    """datasets.py:170-175."""
+    return torch.where(x > thres, x, torch.zeros_like(x))
+
+
+def n_hardest_cutter(x: Tensor, n: int) -> Tensor:
+    """datasets.py:178-186."""
+    highest = torch.sort(x.view(-1))[0][-n]
+    return torch.where(x >= highest, x, torch.zeros_like(x))
+
+
+def sparse_jet_item(row: Tensor, etaBins, phiBins, factor, pre_factor=1, threshold=None, n_hardest=None):
+    """SparseJetDataset.__getitem__ (datasets.py:236-249, noise_factor=None): dataframe row -> (lr, hr)."""
+    img = extract(row[:-1].view(-1, 2).t(), etaBins * pre_factor, phiBins * pre_factor)
+    if threshold:
+        img = threshold_cutter(img, threshold)
+    elif n_hardest:
+        img = n_hardest_cutter(img, n_hardest)
+    img = img[None, ...]
+    if pre_factor > 1:
+        img = sum_pool(img, pre_factor)
+    return sum_pool(img, factor)[0], img[0].clone()
 
 
 # --------------------------------------------------------------------------- train-step losses

@@ -5,9 +5,9 @@ Import by string (the directory name carries a hyphen)::
     import importlib; sr = importlib.import_module("super-resolution_amd")
     G = sr.models.GeneratorRRDB(1, filters=64, num_res_blocks=23, num_upsample=2).cuda()
 """
-from . import _lib, ops, engine, models, evaluation, losses  # noqa: F401
+from . import _lib, ops, engine, models, evaluation, losses, datasets  # noqa: F401
 from .models import (GeneratorRRDB, Markovian_Discriminator, Standard_Discriminator, Conditional_Discriminator, SumPool2d, DenseResidualBlock,  # noqa: F401
                      ResidualInResidualDenseBlock, Conv3x3, discriminator_block, weight_reset, uniform_reset)
 
-__all__ = ["models", "ops", "engine", "_lib", "losses", "GeneratorRRDB", "Markovian_Discriminator", "Standard_Discriminator", "Conditional_Discriminator", "SumPool2d",
+__all__ = ["models", "ops", "engine", "_lib", "losses", "datasets", "GeneratorRRDB", "Markovian_Discriminator", "Standard_Discriminator", "Conditional_Discriminator", "SumPool2d",
            "DenseResidualBlock", "ResidualInResidualDenseBlock", "Conv3x3", "discriminator_block", "weight_reset", "uniform_reset"]

@@ -21,7 +21,7 @@ EXPORTS = [
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
-    "srk_strerror", "srk_version",
+    "srk_jet_extract", "srk_strerror", "srk_version",
 ]
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD = 0, 1, 2
 
@@ -100,6 +100,7 @@ def lib():
                                       C.c_int, C.c_float, _fp, C.c_float, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
         L.srk_conv3x3_dgrad.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
+        L.srk_jet_extract.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]
         L.srk_loss_workspace_bytes.argtypes = [C.POINTER(C.c_size_t)]
         L.srk_sigmoid_fwd.argtypes = [_fp, _fp, C.c_long, C.c_float, C.c_float, _fp]
         L.srk_sigmoid_bwd.argtypes = [_fp, _fp, _fp, C.c_long, C.c_float, _fp]

@@ -269,6 +269,46 @@ __global__ void soft_hist_bwd_kernel(const float* __restrict__ x, long n, const 
   }
 }
 
+// ---------------------------------------------------------------- sparse jet decode (datasets.py:136-145 `extract`)
+// rows [B][row_stride]: interleaved (pos_0, E_0, pos_1, E_1, ...), L pairs per event, zero-padded.  The reference walks
+// the pairs in order, adds E_i to pixel (eta = pos % etaBins, phi = pos // etaBins) and stops at the first E_i == 0.
+// One workgroup per event: the pair list is staged in LDS; entry i OWNS its pixel if no earlier valid entry hits it and
+// then sums all later hits in list order -- the reference's summation order exactly, no atomics, bit-identical.
+// A ThresholdImageCutter (datasets.py:170-175) is folded into the store (thr < 0: none).
+__global__ void jet_extract_kernel(const float* __restrict__ rows, int L, int row_stride, int etaBins, int phiBins, float thr,
+                                   float* __restrict__ out) {
+  extern __shared__ float sh[];                 // [L] pixel index (as int bits), [L] energy
+  int* pix = reinterpret_cast<int*>(sh);
+  float* en = sh + L;
+  __shared__ int first_zero;
+  const int b = blockIdx.x;
+  const float* row = rows + (long)b * row_stride;
+  float* img = out + (long)b * etaBins * phiBins;
+  if (threadIdx.x == 0) first_zero = L;
+  for (int i = threadIdx.x; i < etaBins * phiBins; i += LT) img[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += LT) {
+    const float pos = row[2 * i], e = row[2 * i + 1];
+    const int ip = (int)pos;
+    const int phi = ip / etaBins, eta = ip - phi * etaBins;
+    pix[i] = (ip >= 0 && phi < phiBins) ? eta * phiBins + phi : -1;
+    en[i] = e;
+    if (e == 0.f) atomicMin(&first_zero, i);
+  }
+  __syncthreads();
+  const int n = first_zero;                     // entries [0, n) are added (entry n adds 0 and ends the walk)
+  for (int i = threadIdx.x; i < n; i += LT) {
+    const int p = pix[i];
+    if (p < 0) continue;
+    bool owner = true;
+    for (int j = 0; j < i; ++j) owner = owner && (pix[j] != p);
+    if (!owner) continue;
+    float acc = 0.f;
+    for (int j = i; j < n; ++j) acc += (pix[j] == p) ? en[j] : 0.f;
+    img[p] = (thr < 0.f || acc > thr) ? acc : 0.f;
+  }
+}
+
 int parts_for(long n) {
   long p = (n + (long)LT * 8 - 1) / ((long)LT * 8);      // >= 8 elements per thread
   if (p < 1) p = 1;
@@ -285,6 +325,16 @@ unsigned ew_grid(long n) {
 }
 
 }  // namespace
+
+extern "C" int srk_jet_extract(const float* rows, int B, int L, int row_stride, int etaBins, int phiBins, float threshold, float* out,
+                               void* stream) {
+  if (!rows || !out || B <= 0 || L <= 0 || etaBins <= 0 || phiBins <= 0 || row_stride < 2 * L) return SRK_ERR_BAD_ARG;
+  if (L > 4096) return SRK_ERR_UNSUPPORTED;          // LDS staging of the pair list (32 KB); jets have O(100) constituents
+  hipLaunchKernelGGL(jet_extract_kernel, dim3(B), dim3(LT), (size_t)L * 8, (hipStream_t)stream, rows, L, row_stride, etaBins, phiBins,
+                     threshold, out);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
 
 extern "C" int srk_loss_workspace_bytes(size_t* out) {
   if (!out) return SRK_ERR_BAD_ARG;

@@ -188,9 +188,14 @@ def train(opt, **kwargs):
 
     dataset = kwargs.get("dataset")
     if dataset is None:
-        if opt.dataset_type != "synthetic":
-            raise NotImplementedError("the HDF5 jet datasets (datasets.py) are outside this build; pass dataset=... or use "
-                                      "--dataset_type synthetic")
+        if opt.dataset_type in ("jet", "spjet"):   # datasets.py:316-329, from a .npy file of the dataframe's rows
+            from . import datasets as _ds
+            dataset = _ds.get_dataset(opt.dataset_type, opt.dataset_path, opt.hr_height, opt.hr_width, opt.factor,
+                                      threshold=opt.E_thres)
+        elif opt.dataset_type != "synthetic":
+            raise NotImplementedError("the HDF5/text event datasets (datasets.py) are outside this build; pass dataset=..., use "
+                                      "--dataset_type synthetic, or jet/spjet with a .npy row file")
+    if dataset is None:
         dataset = SyntheticJets(opt.synthetic_batches * opt.batch_size, opt.channels, opt.hr_height, opt.hr_width, opt.factor)
     sampler = None
     if world > 1:
@@ -234,6 +239,8 @@ def train(opt, **kwargs):
             sampler.set_epoch(epoch)
         for i, imgs in enumerate(loader):
             batches_done += 1
+            if "rows" in imgs:                      # raw sparse event rows: the whole batch is decoded by one kernel launch
+                imgs = dataset.decode_batch(imgs["rows"].to(device))
             imgs_lr = imgs["lr"].to(device).float()
             imgs_hr = imgs["hr"].to(device).float()
             in_warm_branch = (not load_chk) or opt.lambda_hist > 0                      # esrgan.py:417

@@ -159,3 +159,14 @@ def test_G11_loss_heads(golden_dir):
         assert close(gen_hist.detach(), d[tag + ".gen"]) and close(real_hist, d[tag + ".real"])
         assert close(loss.detach(), d[tag + ".loss"]) and (gx - torch.from_numpy(d[tag + ".dx"])).abs().max().item() <= 1e-5 * np.abs(d[tag + ".dx"]).max()
         assert close(O.diffable_histogram(x.detach(), d["hist.edges"], sig), d[tag + ".all"])
+
+
+def test_G14_sparse_jet_decode(golden_dir):
+    """O.extract / cutters / sparse_jet_item against images decoded by the reference's datasets.py code path
+    (tools/make_golden_jets.py): duplicates accumulate in list order, the first zero energy ends the walk."""
+    d = np.load(os.path.join(golden_dir, "G14_sparse_jets.npz"))
+    eta, phi, f, L = [int(v) for v in d["cfg"]]
+    for tag, thr, nh, pre in (("plain", None, None, 1), ("thres", 1.5, None, 1), ("nhard", None, 4, 1), ("pre2", None, None, 2)):
+        for e, row in enumerate(d["rows_" + tag]):
+            lr, hr = O.sparse_jet_item(torch.from_numpy(row), eta, phi, f, pre, thr, nh)
+            assert torch.equal(hr, torch.from_numpy(d["hr_" + tag][e])) and torch.equal(lr, torch.from_numpy(d["lr_" + tag][e])), (tag, e)
