@@ -476,6 +476,192 @@ __global__ __launch_bounds__(320) void conv3x3_f32_lw_kernel(const srk_conv_args
   conv_epilogue<BN, MT>(a, acc, smem, n, oh0, ow0, n0, wv, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(2,3) along W ("wino", wp_format 3): the same 16x16 x 64-channel workgroup tile and the same staged
+// halo as the loader-wave kernel, but each output ROW PAIR-OF-COLUMNS (2c, 2c+1) is computed from four products instead
+// of six:   m0 = (d0-d2) u0, m1 = (d1+d2) u1, m2 = (d2-d1) u2, m3 = (d1-d3) u3,   y0 = m0+m1+m2, y1 = m1-m2-m3
+// with u = G w (u0 = w0, u1 = (w0+w1+w2)/2, u2 = (w0-w1+w2)/2, u3 = w2) precomputed by the weight packing (12 "taps"
+// = 3 rows x 4 positions instead of 9).  2/3 of the MFMAs of the direct kernel for the same result up to fp32 rounding
+// (all arithmetic stays fp32; the transform adds ~1 ulp per operand).
+//   * the INPUT transform costs no LDS and no extra wave: a lane reads the four raw pixels (row+r, 2c..2c+3) as float4
+//     (4 channels each) and forms the four transformed A operands with 16 VALU ops, in the shadow of the MFMAs;
+//   * the OUTPUT transform is register-local: the four position accumulators of a wave hold the same (tile, channel)
+//     in the same register of the same lane, and the M index -> (row, column pair) map is chosen so that y0/y1 land
+//     exactly in the accumulator layout conv_epilogue expects (pure register renaming, no shuffles);
+//   * 9 waves: wave 8 stages global->LDS (halo + 12 weight slices per 8-channel chunk), waves 0-7 = 4 row groups x 2
+//     halves of the 64 output channels, four 32x32 accumulators each.
+// M tile of row group g (32 "column pairs"): index i -> rows q = i>>3 in {2g, 2g+1, 8+2g, 9+2g}, pair c = cmap(i&7).
+__device__ __forceinline__ constexpr int wino_cmap(int u) { return (u & 1) | (((u >> 2) & 1) << 1) | (((u >> 1) & 1) << 2); }
+
+template <int MODE>
+__global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_args a) {
+  constexpr int BN = 64;
+  using G = Geo<1, 2>;
+  constexpr int NW4 = 24 * BN;                     // 12 taps x 2 k-halves x BN float4 per chunk
+  constexpr int BUF4 = G::NX4 + NW4;
+  constexpr int NXL = (G::NX4 + 63) / 64;
+  constexpr int NWL = (NW4 + 63) / 64;
+  constexpr int NL = NXL + NWL;
+  constexpr int LB = 8;
+  __shared__ float4 smem[2 * BUF4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + G::TH - 1) / G::TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * G::TH, ow0 = tx * SRK_TW, n0 = blockIdx.y * BN;
+  const int CoutP = (a.Cout + 31) & ~31;
+  const int nq = (a.Cin + 7) >> 3;
+
+  if (wv == 8) {
+    // ------------------------------------------------------------------ loader wave (as in the lw kernel, 24 weight slices)
+    const int Cps_in = a.Cin >> 2;
+    constexpr unsigned OOB = 0x80000000u;
+    long img_elems = (long)a.H * a.W * a.x_ldc;
+    if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+    const float* ximg = a.x + (long)n * img_elems;
+    const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
+    const unsigned wbytes = (unsigned)((long)nq * 24 * CoutP * 16);
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+    unsigned vo[NL];
+    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int idx = lane + i * 64;
+      const int hp = idx >> 1, half = idx & 1;
+      const int hy = hp / G::IW, hx = hp - hy * G::IW;
+      const int ih = ih0 + hy, iw = iw0 + hx;
+      const bool inb = idx < G::NX4 && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+      long off;
+      if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 4 * half;
+      else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 4 * half;
+      vo[i] = inb ? (unsigned)(off * 4) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int idx = lane + i * 64;
+      const int th = idx / BN, co = idx - th * BN;
+      vo[NXL + i] = (idx < NW4 && n0 + co < CoutP) ? (unsigned)((th * CoutP + n0 + co) * 16) : OOB;
+    }
+    const float in_slope = a.in_slope;
+    auto stage = [&](int q, int b) {
+      unsigned xso = (unsigned)(8 * q * 4);
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c8 = 8 * q;
+        const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+      }
+      const unsigned wso = (unsigned)(q * 24 * CoutP * 16);
+      float4* dst = smem + b * BUF4;
+#pragma unroll
+      for (int i0 = 0; i0 < NL; i0 += LB) {
+        f32x4 r[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int i = i0 + j;
+          if (i < NL)
+            r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i < NXL ? xrsrc : wrsrc, vo[i], i < NXL ? xso : wso, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int i = i0 + j;
+          if (i >= NL) continue;
+          float4 v = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
+          if (i < NXL) {
+            if (in_slope != 1.f) {
+              v.x = v.x > 0.f ? v.x : v.x * in_slope; v.y = v.y > 0.f ? v.y : v.y * in_slope;
+              v.z = v.z > 0.f ? v.z : v.z * in_slope; v.w = v.w > 0.f ? v.w : v.w * in_slope;
+            }
+            const int idx = lane + i * 64;
+            if (idx < G::NX4) dst[idx] = v;
+          } else {
+            const int idx = lane + (i - NXL) * 64;
+            if (idx < NW4) dst[G::NX4 + idx] = v;
+          }
+        }
+      }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+      if (q + 1 < nq) stage(q + 1, (q & 1) ^ 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- MFMA waves
+  const int wg = wv & 3, nh = wv >> 2;             // row group, output-channel half
+  f32x16 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int tq = l32 >> 3, tc = wino_cmap(l32 & 7);
+  const int trow = 8 * (tq >> 1) + 2 * wg + (tq & 1);
+  const int abase = (trow * G::IW + 2 * tc) * 2 + hl;             // float4 index of raw pixel d0 for tap row 0
+  const int wbase = G::NX4 + hl * BN + 32 * nh + l32;
+  f32x4 dn[4], bn[4], V[4], Bv[4];
+  auto ld_row = [&](int b, int r) {
+    const f32x4* xb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + abase + r * G::IW * 2;
+    const f32x4* wb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + wbase + (4 * r) * 2 * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dn[j] = xb[2 * j];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bn[p] = wb[p * 2 * BN];
+  };
+  auto transform = [&]() {
+    V[0] = dn[0] - dn[2]; V[1] = dn[1] + dn[2]; V[2] = dn[2] - dn[1]; V[3] = dn[1] - dn[3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Bv[p] = bn[p];
+  };
+  auto mfma_row = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][e], Bv[p][e], acc[p], 0, 0, 0);
+  };
+  __syncthreads();                               // chunk 0 staged by the loader
+  ld_row(0, 0);
+  transform();
+  for (int q = 0; q < nq; ++q) {
+    const int b = q & 1;
+    const bool more = q + 1 < nq;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      ld_row(b, r + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row();
+      __builtin_amdgcn_sched_barrier(0);
+      transform();
+    }
+    __syncthreads();                             // buffer b consumed (row 2 is in registers); b^1 staged
+    if (more) ld_row(b ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row();                                  // tap row 2
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) transform();
+  }
+  // output transform + register renaming into conv_epilogue's layout: source register 4*tq + s holds column pair
+  // c = cmap(4*hl + s) of row tq; destination tile m = tq>>1, register 4*(2*(tq&1) + (s>>1)) + 2*(s&1) + e.
+  f32x16 out[2][1];
+#pragma unroll
+  for (int tq2 = 0; tq2 < 4; ++tq2)
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+      const int src = 4 * tq2 + sx;
+      const float m0 = acc[0][src], m1 = acc[1][src], m2 = acc[2][src], m3 = acc[3][src];
+      const int dst = 4 * (2 * (tq2 & 1) + (sx >> 1)) + 2 * (sx & 1);
+      out[tq2 >> 1][0][dst] = (m0 + m1) + m2;
+      out[tq2 >> 1][0][dst + 1] = (m1 - m2) - m3;
+    }
+  conv_epilogue<32, 2>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
+}
+
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
 int launch_k(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * MT);
@@ -489,6 +675,15 @@ int launch_k(const srk_conv_args& a, hipStream_t st) {
 // The global->LDS DMA variant (DMA = true) is correct but measured SLOWER than register staging on gfx950
 // (80 vs 73.6 cycles per MFMA at one workgroup per CU: each buffer_load...lds piece costs the issuing MFMA wave
 // more issue time than a buffer_load + ds_write_b128 pair), so it is not dispatched.
+template <int MODE>
+int launch_wino(const srk_conv_args& a, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * 2);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+  hipLaunchKernelGGL((conv3x3_f32_wino_kernel<MODE>), grid, dim3(576), 0, st, a);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
 template <int BN, int MODE>
 int launch_lw(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * 2);
@@ -540,6 +735,15 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
     if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
     return srk_launch_conv_bf16x3(a, st);
+  }
+  if (a.wp_format == 3) {
+    // Winograd F(2,3)-along-W fragments (srk_pack_weights with fmt 3): stride 1, 8-channel chunks, 64-channel output tiles
+    if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
+    if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cout % 64) || (a.Cin % 8)) return SRK_ERR_UNSUPPORTED;
+    if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 8))) return SRK_ERR_UNSUPPORTED;
+    if ((a.x_ldc % 4) || (a.x_coff % 4) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
+    if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
+    return a.in_mode == SRK_IN_PLAIN ? launch_wino<SRK_IN_PLAIN>(a, st) : launch_wino<SRK_IN_UNSHUFFLE>(a, st);
   }
   if (a.wp_format != 0) return SRK_ERR_UNSUPPORTED;
   if (!a.x || !a.y || !a.wp) return SRK_ERR_BAD_ARG;

@@ -6,7 +6,7 @@
 // (rows 2wv, 2wv+1 of the m-th 8-row group), channel = n0 + 32t + l32.
 template <int BN, int MT, bool ROWTILE = false>
 __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float4* smem, int n, int oh0,
-                                              int ow0, int n0, int wv, int lane) {
+                                              int ow0, int n0, int wv, int lane, int lds_slot = -1) {
   constexpr int NTN = BN / 32;
   constexpr int TILE_H = ROWTILE ? 4 * MT : SRK_TH * MT;   // ROWTILE: a 32-pixel M tile is ONE image row (tile 4MT x 32)
   constexpr int TILE_W = ROWTILE ? 32 : SRK_TW;
@@ -31,7 +31,7 @@ __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&a
     // Transpose each 32 px x 32 ch accumulator tile through this wave's private 4 KB of LDS so that a lane
     // owns 4 consecutive channels of one pixel: 16-byte loads/stores, 4x fewer store instructions (the
     // store tail is issue-bound).  The main loop's last barrier has retired every other use of the LDS.
-    float* ls = reinterpret_cast<float*>(smem) + wv * 1024;
+    float* ls = reinterpret_cast<float*>(smem) + (lds_slot < 0 ? wv : lds_slot) * 1024;   // private 4 KB per wave
     float4* ls4 = reinterpret_cast<float4*>(ls);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {

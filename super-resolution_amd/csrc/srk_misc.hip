@@ -7,11 +7,14 @@ namespace {
 
 // ---------------------------------------------------------------- weight packing
 // work item = one float4 of dst: (q_local, tap, h, m) -> 4 consecutive k.
+// fmt 3 ("wino"): 12 taps = 3 kernel rows x 4 Winograd F(2,3) positions along the kernel's column axis,
+//   u0 = w0, u1 = (w0 + w1 + w2)/2, u2 = (w0 - w1 + w2)/2, u3 = w2   (w_s = the row's three column taps)
 __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
   const int h = (int)(t & 1); t >>= 1;
-  const int tap = (int)(t % 9); t /= 9;
+  const int ntap = e.fmt == 3 ? 12 : 9;
+  const int tap = (int)(t % ntap); t /= ntap;
   const int ql = (int)t;                      // chunk index relative to k_off/8
   const int q = (e.k_off >> 3) + ql;
   const int Cps = e.src_cout >> 2;
@@ -22,20 +25,30 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
     const int kr = k - e.k_off;               // k relative to this entry
     float val = 0.f;
     if (m < e.M && kr >= 0 && kr < e.k_len) {
+      const float* w9;                          // the 9 taps of this (output, input) channel pair
       if (!e.transpose) {
         int o = m;
         if (e.ps) o = 4 * (m % Cps) + m / Cps;
-        val = e.src[((long)o * e.src_cin + e.c_begin + kr) * 9 + tap];
+        w9 = e.src + ((long)o * e.src_cin + e.c_begin + kr) * 9;
       } else {
         int o = kr;
         if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
-        val = e.src[((long)o * e.src_cin + e.c_begin + m) * 9 + (8 - tap)];
+        w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
+      }
+      if (e.fmt == 3) {
+        const int r = tap >> 2, p = tap & 3;
+        float w0, w1, w2;
+        if (!e.transpose) { w0 = w9[3 * r]; w1 = w9[3 * r + 1]; w2 = w9[3 * r + 2]; }
+        else { w0 = w9[8 - 3 * r]; w1 = w9[7 - 3 * r]; w2 = w9[6 - 3 * r]; }      // data gradient: taps flipped
+        val = p == 0 ? w0 : p == 1 ? 0.5f * ((w0 + w1) + w2) : p == 2 ? 0.5f * ((w0 - w1) + w2) : w2;
+      } else {
+        val = e.transpose ? w9[8 - tap] : w9[tap];
       }
       val *= e.scale;
     }
     v[j] = val;
   }
-  float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * 9 + tap) * 2 + h) * Mp + m;
+  float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * ntap + tap) * 2 + h) * Mp + m;
   *d = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -156,13 +169,17 @@ extern "C" size_t srk_packed_floats(int K, int M) {
   return (size_t)srk_div_up(K, 16) * 2 * 9 * 2 * srk_round_up(M, 32) * 4;
 }
 
+extern "C" size_t srk_packed_floats_wino(int K, int M) {
+  return (size_t)srk_div_up(K, 16) * 2 * 12 * 2 * srk_round_up(M, 32) * 4;
+}
+
 extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   if (!e || !total || n <= 0) return SRK_ERR_BAD_ARG;
   int64_t acc = 0;
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
-    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3)) return SRK_ERR_BAD_ARG;
     if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
     e[i].elem_begin = acc;
     // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
@@ -170,7 +187,7 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
     int k_end = e[i].k_off + e[i].k_len;
     int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
     // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
-    acc += (int64_t)nq * 9 * 2 * srk_round_up(e[i].M, 32);
+    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : 9) * 2 * srk_round_up(e[i].M, 32);
   }
   *total = acc;
   return SRK_OK;

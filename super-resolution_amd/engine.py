@@ -168,24 +168,34 @@ class GeneratorEngine:
         F_, C_ = g.filters, g.channels
         self.flat_f, self.flat_b = _Flat(), _Flat()
         # one table per (direction, fragment format)
-        self.tab_f, self.tab_b = [L.PackTable(device, 0), L.PackTable(device, 1)], [L.PackTable(device, 0), L.PackTable(device, 1)]
+        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3)}
+        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3)}
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
         bf = self.precision in ("bf16x3", "bf16")
         self._built_precision = self.precision
 
+        # exact-fp32 mode: stride-1 convs with 64-multiple outputs run the Winograd F(2,3)-along-W kernel (2/3 of the MFMAs)
+        wino = (not bf) and os.environ.get("SRK_WINOGRAD", "1") != "0"
+
         def fmt_of(K, M):
-            return 1 if (bf and K % 16 == 0 and M >= 16) else 0
+            if bf:
+                return 1 if (K % 16 == 0 and M >= 16) else 0
+            return 3 if (wino and L.wino_eligible(K, M)) else 0
 
         def simple(name, conv, ps=False, need_bwd=True):
             co, ci = conv.weight.shape[:2]
-            fi = self.flat_f.reserve(L.packed_floats(ci, co))
-            self.fmt_f[fi] = fmt_of(ci, co) if (not ps or (co // 4) % 4 == 0) else 0
+            ff = fmt_of(ci, co) if (not ps or (co // 4) % 4 == 0) else 0
+            fi = self.flat_f.reserve(L.packed_floats(ci, co, ff))
+            self.fmt_f[fi] = ff
             jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=ci, ps=ps)))
             bi = None
             if need_bwd:
-                bi = self.flat_b.reserve(L.packed_floats(co, ci))
-                self.fmt_b[bi] = fmt_of(co, ci) if (not ps or (co // 4) % 16 == 0) else 0
+                fb = fmt_of(co, ci) if (not ps or (co // 4) % 16 == 0) else 0
+                if fb == 3 and conv.stride[0] != 1:
+                    fb = 0
+                bi = self.flat_b.reserve(L.packed_floats(co, ci, fb))
+                self.fmt_b[bi] = fb
                 jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=co, transpose=True, ps=ps)))
             return fi, bi
 
@@ -193,13 +203,15 @@ class GeneratorEngine:
             p = DrbPack(F_)
             for k in range(1, 6):
                 w = getattr(d, f"b{k}")[0].weight
-                p.fwd[k] = self.flat_f.reserve(L.packed_floats(k * F_, F_))
-                self.fmt_f[p.fwd[k]] = fmt_of(k * F_, F_)
+                ff = fmt_of(k * F_, F_)
+                p.fwd[k] = self.flat_f.reserve(L.packed_floats(k * F_, F_, ff))
+                self.fmt_f[p.fwd[k]] = ff
                 jobs_f.append((w, p.fwd[k], dict(M=F_, k_off=0, k_len=k * F_, K_total=k * F_)))
             for m in range(0, 5):
                 K = (5 - m) * F_
-                p.bwd[m] = self.flat_b.reserve(L.packed_floats(K, F_))
-                self.fmt_b[p.bwd[m]] = fmt_of(K, F_) if F_ % 16 == 0 else 0
+                fb = fmt_of(K, F_) if (F_ % 16 == 0 or not bf) else 0
+                p.bwd[m] = self.flat_b.reserve(L.packed_floats(K, F_, fb))
+                self.fmt_b[p.bwd[m]] = fb
                 for k in range(5, m, -1):     # input slice (5-k) of the dy buffer carries dy_k
                     w = getattr(d, f"b{k}")[0].weight
                     jobs_b.append((w, p.bwd[m], dict(M=F_, k_off=(5 - k) * F_, k_len=F_, K_total=K, transpose=True,
@@ -228,7 +240,7 @@ class GeneratorEngine:
             self.tab_f[self.fmt_f[fi]].add(w.data, self.flat_f.slices[fi], **kw)
         for w, bi, kw in jobs_b:
             self.tab_b[self.fmt_b[bi]].add(w.data, self.flat_b.slices[bi], **kw)
-        for t in self.tab_f + self.tab_b:
+        for t in list(self.tab_f.values()) + list(self.tab_b.values()):
             t.finalize()
 
     def _ensure_packed(self, need_bwd: bool):
@@ -242,10 +254,10 @@ class GeneratorEngine:
             self._build_tables(dev)
             self._sig = sig
         if need_bwd:
-            for t in self.tab_b:
+            for t in self.tab_b.values():
                 t.run()
             return
-        for t in self.tab_f:
+        for t in self.tab_f.values():
             t.run()
         # packed-order biases of the PixelShuffle convs (o' = ij*F + c  <->  o = 4c + ij)
         self.ps_bias = {}

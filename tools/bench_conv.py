@@ -16,17 +16,18 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     N, H, W, F = int(os.environ.get("N", 16)), 64, 64, 64
+    FMT = int(os.environ.get("FMT", 0))          # 0: direct fp32 kernel, 3: Winograd F(2,3)-along-W kernel
     dev = "cuda"
     buf = torch.randn(N, H, W, 5 * F, device=dev)
     out = torch.empty(N, H, W, F, device=dev)
     for k in range(1, 6):
         ci = k * F
         w = torch.randn(F, ci, 3, 3, device=dev) * 0.02
-        wp = torch.empty(L.packed_floats(ci, F), device=dev)
-        t = L.PackTable(buf.device); t.add(w, wp, M=F, k_off=0, k_len=ci, K_total=ci); t.run()
+        wp = torch.empty(L.packed_floats(ci, F, FMT), device=dev)
+        t = L.PackTable(buf.device, FMT); t.add(w, wp, M=F, k_off=0, k_len=ci, K_total=ci); t.run()
         b = torch.zeros(F, device=dev)
         fl = 2.0 * N * H * W * F * ci * 9
-        dt = timeit(lambda: L.conv3x3(L.View(buf, 0, ci), wp, b, L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, slope=0.01))
+        dt = timeit(lambda: L.conv3x3(L.View(buf, 0, ci), wp, b, L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, slope=0.01, wp_format=FMT))
         print(f"fwd  Cin={ci:3d}->64  {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF/s")
         dw = torch.empty(F, ci, 3, 3, device=dev); db = torch.empty(F, device=dev)
         dt = timeit(lambda: L.conv3x3_wgrad(L.View(buf, 0, ci), L.View(out), dw, db, N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F))
@@ -35,10 +36,10 @@ def main():
     Hh = 256
     x = torch.randn(N, Hh, Hh, F, device=dev); y = torch.empty(N, Hh, Hh, F, device=dev)
     w = torch.randn(F, F, 3, 3, device=dev) * 0.02
-    wp = torch.empty(L.packed_floats(F, F), device=dev)
-    t = L.PackTable(x.device); t.add(w, wp, M=F, k_off=0, k_len=F, K_total=F); t.run()
+    wp = torch.empty(L.packed_floats(F, F, FMT), device=dev)
+    t = L.PackTable(x.device, FMT); t.add(w, wp, M=F, k_off=0, k_len=F, K_total=F); t.run()
     fl = 2.0 * N * Hh * Hh * F * F * 9
-    dt = timeit(lambda: L.conv3x3(L.View(x), wp, None, L.View(y), N=N, H=Hh, W=Hh, OH=Hh, OW=Hh, Cin=F, Cout=F, slope=0.01))
+    dt = timeit(lambda: L.conv3x3(L.View(x), wp, None, L.View(y), N=N, H=Hh, W=Hh, OH=Hh, OW=Hh, Cin=F, Cout=F, slope=0.01, wp_format=FMT))
     print(f"fwd HR 64->64 256^2 {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF/s")
     w1 = torch.randn(1, F, 3, 3, device=dev) * 0.02
     wp1 = torch.empty(L.packed_floats(F, 1), device=dev)
