@@ -15,6 +15,7 @@
 // Mirrors: nn.Conv2d/LeakyReLU/cat/mul+add/PixelShuffle of /root/reference/models.py:19-21,36-41,53,
 // 63,67,86-90,97-99,126,142-145,168 (forward) and their autograd data-gradients.
 #include "srk_internal.h"
+#include <type_traits>
 #include "srk_epilogue.h"
 #include <stdlib.h>
 
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
   const int CoutP = (a.Cout + 31) & ~31;
   const int nq = (a.Cin + 7) >> 3;
 
+  SRK_STAMP_AT(0);
   if (wv == 8) {
     // ------------------------------------------------------------------ loader wave (as in the lw kernel, 24 weight slices)
     const int Cps_in = a.Cin >> 2;
@@ -605,47 +607,61 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
   const int trow = 8 * (tq >> 1) + 2 * wg + (tq & 1);
   const int abase = (trow * G::IW + 2 * tc) * 2 + hl;             // float4 index of raw pixel d0 for tap row 0
   const int wbase = G::NX4 + hl * BN + 32 * nh + l32;
-  f32x4 dn[4], bn[4], V[4], Bv[4];
-  auto ld_row = [&](int b, int r) {
+  // B fragments are double-buffered by compile-time parity (row steps alternate 0,1,0 | 1,0,1 over a PAIR of chunks), so
+  // every ds_read lands in the register the MFMAs will use -- no copies in the loop.
+  f32x4 dn[4], V[2][4], Bv[2][4];
+  auto ld_row = [&](int b, int r, int par) {
     const f32x4* xb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + abase + r * G::IW * 2;
     const f32x4* wb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + wbase + (4 * r) * 2 * BN;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dn[j] = xb[2 * j];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) bn[p] = wb[p * 2 * BN];
+    for (int p = 0; p < 4; ++p) Bv[par][p] = wb[p * 2 * BN];
   };
-  auto transform = [&]() {
-    V[0] = dn[0] - dn[2]; V[1] = dn[1] + dn[2]; V[2] = dn[2] - dn[1]; V[3] = dn[1] - dn[3];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) Bv[p] = bn[p];
+  auto transform = [&](int par) {
+    V[par][0] = dn[0] - dn[2]; V[par][1] = dn[1] + dn[2]; V[par][2] = dn[2] - dn[1]; V[par][3] = dn[1] - dn[3];
   };
-  auto mfma_row = [&]() {
+  auto mfma_row = [&](int par) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][e], Bv[p][e], acc[p], 0, 0, 0);
+      for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[par][p][e], Bv[par][p][e], acc[p], 0, 0, 0);
   };
-  __syncthreads();                               // chunk 0 staged by the loader
-  ld_row(0, 0);
-  transform();
-  for (int q = 0; q < nq; ++q) {
+  // one chunk whose row 0 operands sit in parity P0 (already loaded and transformed); leaves the next chunk's row 0 in
+  // parity P0 ^ 1
+  auto chunk = [&](int q, auto P0c) {
+    constexpr int P0 = decltype(P0c)::value;
     const int b = q & 1;
     const bool more = q + 1 < nq;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      ld_row(b, r + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_row();
-      __builtin_amdgcn_sched_barrier(0);
-      transform();
-    }
+    ld_row(b, 1, P0 ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(P0);
+    __builtin_amdgcn_sched_barrier(0);
+    transform(P0 ^ 1);
+    ld_row(b, 2, P0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(P0 ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    transform(P0);
     __syncthreads();                             // buffer b consumed (row 2 is in registers); b^1 staged
-    if (more) ld_row(b ^ 1, 0);
+    if (more) ld_row(b ^ 1, 0, P0 ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_row();                                  // tap row 2
+    mfma_row(P0);                                // tap row 2
     __builtin_amdgcn_sched_barrier(0);
-    if (more) transform();
+    if (more) transform(P0 ^ 1);
+  };
+  SRK_STAMP_AT(1);
+  __syncthreads();                               // chunk 0 staged by the loader
+  SRK_STAMP_AT(2);
+  ld_row(0, 0, 0);
+  transform(0);
+  int q = 0;
+  for (; q + 1 < nq; q += 2) {
+    chunk(q, std::integral_constant<int, 0>{});
+    chunk(q + 1, std::integral_constant<int, 1>{});
   }
+  if (q < nq) chunk(q, std::integral_constant<int, 0>{});
+  SRK_STAMP_AT(3);
   // output transform + register renaming into conv_epilogue's layout: source register 4*tq + s holds column pair
   // c = cmap(4*hl + s) of row tq; destination tile m = tq>>1, register 4*(2*(tq&1) + (s>>1)) + 2*(s&1) + e.
   f32x16 out[2][1];
@@ -660,6 +676,7 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
       out[tq2 >> 1][0][dst + 1] = (m1 - m2) - m3;
     }
   conv_epilogue<32, 2>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
+  SRK_STAMP_AT(4);
 }
 
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>

@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, re, sys
 
 
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv")))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -24,7 +24,7 @@ def load(d, counter):
 
 
 def short(name):
-    m = re.search(r"(conv3x3_f32_lw_kernel<[^>]*>|conv3x3_f32_kernel<[^>]*>|wgrad_c1_kernel<[^>]*>|wgrad_f32_kernel<[^>]*>|wgrad_reduce_kernel|pack_kernel)", name)
+    m = re.search(r"(conv3x3_f32_wino_kernel<[^>]*>|conv3x3_f32_lw_kernel<[^>]*>|conv3x3_f32_kernel<[^>]*>|wgrad_prereduce_kernel|wgrad_c1_kernel<[^>]*>|wgrad_f32_kernel<[^>]*>|wgrad_reduce_kernel|pack_kernel)", name)
     return m.group(1) if m else None
 
 
