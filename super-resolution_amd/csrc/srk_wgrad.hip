@@ -43,7 +43,7 @@ struct WProb {
 
 struct WBatch {
   int N, H, W, OH, OW;
-  int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode;
+  int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode, wino;
   WProb prob[MAX_PROB];
   unsigned char c_prob[MAX_CHUNK], c_cy[MAX_CHUNK], c_cz[MAX_CHUNK];
 };
@@ -275,6 +275,193 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       for (int reg = 0; reg < 16; ++reg) {
         const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
         dst[(tap * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = acc[tap][reg];
+      }
+  }
+  if (do_bias && ks == 0) {
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Winograd weight gradient (stride 1, 16-byte-addressable views, no input activation): the transposed F(2,3) algorithm
+// along the image row.  For an output column pair (g0, g1) = dy[.., 2c], dy[.., 2c+1] and the four inputs d0..d3 =
+// x[.., 2c-1 .. 2c+2] of kernel row r, the three column taps  dW_s += g0 d_s + g1 d_{s+1}  (6 products) follow from 4:
+//     a = (g0, g0+g1, g0-g1, g1),  b = (d0-d2, d1+d2, d2-d1, d1-d3),  M_p += a_p b_p
+//     dW_0 = M0 + (M1+M2)/2,  dW_1 = (M1-M2)/2,  dW_2 = (M1+M2)/2 - M3
+// so the MFMA K index runs over column PAIRS and each wave keeps 12 (3 rows x 4 positions) instead of 9 accumulator tiles:
+// 12 MFMAs per pair instead of 18 (2/3 of the matrix work); the G^T combination is applied once, in registers, before
+// the partial block is written, so the reduction kernels and the partial layout are unchanged.
+// 192 accumulator VGPRs leave no room for staging registers: tiles go global -> LDS by DMA (buffer_load ... lds, 16 B per
+// lane, zero fill through the buffer range check), double-buffered, one barrier per tile.  8 waves = 4 (cout, cin) 32x32
+// tiles x 2 pixel halves (summed through LDS at the end, fixed order).
+__device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+}
+
+constexpr int WW_THREADS = 512;
+constexpr int WW_TILE_FLOATS = WGeo<1>::TP * 64 + WGeo<1>::NHP * 64;     // 11008 floats = 44,032 B per buffer
+
+template <int DYMODE>
+__global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch B, float* part, float* pbias) {
+  using G = WGeo<1>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * WW_TILE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform, provably so (SGPR): DMA bases, branches
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int wa = wv & 1, wb = (wv >> 1) & 1, ks = wv >> 2;
+  const int p = blockIdx.x, chunk = blockIdx.y;
+  // everything about the problem is workgroup-uniform: keep it in SGPRs (the byte tables are read through a VGPR otherwise,
+  // which would turn every buffer descriptor below into a waterfall loop)
+  const int pi = __builtin_amdgcn_readfirstlane(B.c_prob[chunk]);
+  const int cy = __builtin_amdgcn_readfirstlane(B.c_cy[chunk]), cz = __builtin_amdgcn_readfirstlane(B.c_cz[chunk]);
+  const WProb& a = B.prob[pi];
+  const int cin0 = cy * 64, cout0 = cz * 64;
+  const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
+  const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
+  const int Cps = a.Cout >> 2;
+
+  f32x16 acc[12];
+#pragma unroll
+  for (int t = 0; t < 12; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const int t_begin = p * B.tpb;
+  int t_end = t_begin + B.tpb;
+  if (t_end > B.total_tiles) t_end = B.total_tiles;
+
+  const long x_img = (long)B.H * B.W * a.x_ldc;
+  const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
+  const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
+  const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
+  const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
+  constexpr int NPIECE = G::TP * 16 + G::NHP * 16;                 // 16-byte pieces per tile: 1024 (dy) + 1728 (x)
+  constexpr int NINST = (NPIECE + 63) / 64;                        // wave-wide DMA instructions per tile (43)
+  static_assert(NPIECE % 64 == 0, "whole DMA instructions");
+  // A DMA instruction moves 64 pieces = 4 consecutive pixels x 16 channel quads: the lane's channel quad c4 and pixel
+  // sub-index lp never change, only the pixel group (wave-uniform) does.
+  const int c4 = lane & 15, lp = lane >> 4;
+  const int co = cout0 + 4 * c4, ci = cin0 + 4 * c4;
+  int dyc, dyij = 0;
+  if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
+  const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
+  // stage tile `tile` into buffer `b`: wave w issues instructions w, w+8, ...
+  auto stage = [&](int tile, int b) {
+    int tt = tile;
+    const int tx = tt % B.tilesW; tt /= B.tilesW;
+    const int ty = tt % B.tilesH; tt /= B.tilesH;
+    const int n = tt;
+    const int oh0 = ty * G::TH, ow0 = tx * WTW;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
+    float* buf = smem + b * WW_TILE_FLOATS;
+#pragma unroll
+    for (int i0 = 0; i0 < (NINST + 7) / 8; ++i0) {
+      const int i = i0 * 8 + wv;                                   // wave-uniform instruction index
+      if (i >= NINST) break;
+      if (i < G::TP * 16 / 64) {
+        const int oh = oh0 + (i >> 2), ow = ow0 + 4 * (i & 3) + lp; // pixel 4i + lp of the 4 x 16 tile
+        unsigned off;
+        if (DYMODE == SRK_IN_UNSHUFFLE) off = (unsigned)((((2 * oh + (dyij >> 1)) * (2 * B.OW) + 2 * ow + (dyij & 1)) * a.dy_ldc + dyc) * 4);
+        else off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + dyc) * 4);
+        const bool ok = oh < B.OH && ow < B.OW && co_ok;
+        wdma16(dr, buf + i * 256, ok ? off : W_OOB);
+      } else {
+        const int hp = 4 * (i - G::TP * 16 / 64) + lp;            // halo pixel 0..107
+        const int hy = hp / G::IW, hx = hp - hy * G::IW;
+        const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+        const bool ok = ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci_ok;
+        const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
+        wdma16(xr, buf + i * 256, ok ? off : W_OOB);
+      }
+    }
+  };
+
+  // per-lane LDS offsets (floats) of pair (row 2ks + kk/4, column pair 2*(kk%4) + hl) for k-step kk = 0..7
+  const int aoff = ((2 * ks) * 16 + 2 * hl) * 64 + 32 * wa + l32;                      // g0; g1 = + 64
+  const int boff = G::TP * 64 + ((2 * ks) * G::IW + 2 * hl) * 64 + 32 * wb + l32;      // d0 of kernel row 0; d_j = + 64 j
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  __syncthreads();
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = (tile - t_begin) & 1;
+    if (tile + 1 < t_end) stage(tile + 1, b ^ 1);
+    if (active) {
+      const float* ap = smem + b * WW_TILE_FLOATS + aoff;
+      const float* bp = smem + b * WW_TILE_FLOATS + boff;
+      float g[2][2], d[2][3][4];
+      auto ld_k = [&](int q, int kk) {
+        const int o = ((kk >> 2) * 16 + 4 * (kk & 3)) * 64, ox = ((kk >> 2) * G::IW + 4 * (kk & 3)) * 64;
+        g[q][0] = ap[o]; g[q][1] = ap[o + 64];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[q][r][j] = bp[ox + (r * G::IW + j) * 64];
+      };
+      ld_k(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < 8) ld_k(cur ^ 1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float g0 = g[cur][0], g1 = g[cur][1];
+        const float av[4] = {g0, g0 + g1, g0 - g1, g1};
+        if (do_bias) bsum += g0 + g1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float bv[4] = {d[cur][r][0] - d[cur][r][2], d[cur][r][1] + d[cur][r][2], d[cur][r][2] - d[cur][r][1], d[cur][r][1] - d[cur][r][3]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[4 * r + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[4 * r + q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();               // next tile landed (vmcnt drained by the barrier's fence), this one fully read
+  }
+
+  // G^T: the nine tap tiles from the twelve position tiles (in place: tap 3r+s <- acc[4r..4r+3])
+  f32x16 tap[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float m0 = acc[4 * r][e], m1 = acc[4 * r + 1][e], m2 = acc[4 * r + 2][e], m3 = acc[4 * r + 3][e];
+      const float hs = 0.5f * (m1 + m2);
+      tap[3 * r][e] = m0 + hs;
+      tap[3 * r + 1][e] = 0.5f * (m1 - m2);
+      tap[3 * r + 2][e] = hs - m3;
+    }
+  // fixed-order sum of the two pixel halves through LDS, three taps at a time ([slot = wa + 2 wb][tap][reg][lane])
+  const int slot = wv & 3;
+  for (int r3 = 0; r3 < 3; ++r3) {
+    if (ks == 1) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) smem[((slot * 3 + t) * 16 + reg) * 64 + lane] = tap[3 * r3 + t][reg];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tap[3 * r3 + t][reg] += smem[((slot * 3 + t) * 16 + reg) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (ks == 1) smem[slot * 64 + lane] = bsum;
+  __syncthreads();
+  if (ks == 0) bsum += smem[slot * 64 + lane];
+
+  if (active && ks == 0) {
+    float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+        dst[(t * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = tap[t][reg];
       }
   }
   if (do_bias && ks == 0) {
@@ -647,6 +834,8 @@ __global__ void wgrad_c1_reduce_kernel(const WBatch B, const float* __restrict__
   else if (a.db) { float* d = a.db + o; *d = a.accumulate ? *d + s : s; }
 }
 
+bool is_vec(const srk_wgrad_args& a);
+
 int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (!args || n <= 0 || n > MAX_PROB) return SRK_ERR_BAD_ARG;
   const srk_wgrad_args& a0 = args[0];
@@ -686,7 +875,14 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (small_target < 0) { const char* e = getenv("SRK_WGRAD_SMALL_TARGET"); small_target = e ? atoi(e) : 512; }
   static int tiny_target = -1;        // single-chunk problems with <= 32 input channels (discriminator layers)
   if (tiny_target < 0) { const char* e = getenv("SRK_WGRAD_TINY_TARGET"); tiny_target = e ? atoi(e) : 512; }
+  // Winograd kernel (8 waves, one workgroup per CU): stride 1, 16-byte views, no input activation, >= 64 channels each way
+  static int wino_env = -1;
+  if (wino_env < 0) { const char* e = getenv("SRK_WGRAD_WINO"); wino_env = e ? atoi(e) : 1; }
+  B.wino = wino_env && a0.stride == 1 && a0.precision == 0;
+  for (int i = 0; i < n; ++i)
+    B.wino = B.wino && is_vec(args[i]) && args[i].in_slope == 1.f && args[i].Cout > 32 && args[i].Cin > 32 && args[i].precision == 0;
   int target = (nc <= 2 ? small_target : 512) / nc;
+  if (B.wino) target = 256 / nc;
   if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
@@ -760,7 +956,9 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     if (ks_env < 0) { const char* e = getenv("SRK_WGRAD_KSPLIT"); ks_env = e ? atoi(e) : 1; }
     if (!ks_env) ksp = 1;
   }
-  if (DYMODE == SRK_IN_PLAIN && ksp == 4)
+  if (S == 1 && VEC && B.wino)
+    hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), grid, dim3(WW_THREADS), 0, st, B, part, pbias);
+  else if (DYMODE == SRK_IN_PLAIN && ksp == 4)
     hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 2)
     hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
