@@ -156,7 +156,9 @@ def test_conv_dgrad_unshuffle(U):
                                                   (320, 64, 64, 64, 1, 2), (3, 64, 8, 8, 1, 1), (64, 64, 75, 75, 2, 1),
                                                   # pixel-split ("KS") variants: 1 or 2 live wave tiles per chunk
                                                   (16, 32, 33, 40, 1, 2), (32, 64, 20, 24, 2, 2), (64, 32, 20, 24, 1, 1),
-                                                  (48, 24, 11, 13, 2, 2), (128, 32, 16, 16, 1, 1), (16, 96, 16, 16, 2, 1)])
+                                                  (48, 24, 11, 13, 2, 2), (128, 32, 16, 16, 1, 1), (16, 96, 16, 16, 2, 1),
+                                                  # Winograd weight-gradient kernel (stride 1, > 32 channels each way): odd / ragged extents
+                                                  (64, 64, 15, 17, 1, 2), (128, 128, 7, 9, 1, 1), (64, 192, 1, 1, 1, 3), (96, 64, 33, 3, 1, 1)])
 def test_conv_wgrad(U, ci, co, h, w, stride, n):
     L = U.L
     x = _rand((n, ci, h, w), 22)
@@ -175,6 +177,22 @@ def test_conv_wgrad(U, ci, co, h, w, stride, n):
     L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=oh, OW=ow, Cin=ci, Cout=co, stride=stride,
                     scale=0.5, accumulate=True)
     assert U.rel_err(dw.cpu(), 1.5 * wt.grad) < TOL
+
+
+def test_conv_wgrad_unshuffle_wino(U):
+    """upsampling conv at F=64 (Cout = 256): dy read through SRK_IN_UNSHUFFLE by the Winograd weight-gradient kernel."""
+    L = U.L
+    n, F_, h, w = 2, 64, 8, 12
+    x = _rand((n, F_, h, w), 91)
+    wt = _rand((4 * F_, F_, 3, 3), 92, 0.05).requires_grad_(True)
+    b = torch.zeros(4 * F_, requires_grad=True)
+    y = O.pixel_shuffle(O.conv3x3(x, wt, b), 2)
+    g = _rand(y.shape, 93)
+    y.backward(g)
+    dw = torch.full((4 * F_, F_, 3, 3), float("nan"), device="cuda")
+    db = torch.full((4 * F_,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(g)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, dy_mode=L.IN_UNSHUFFLE)
+    assert U.rel_err(dw.cpu(), wt.grad) < TOL and U.rel_err(db.cpu(), b.grad) < TOL
 
 
 def test_conv_wgrad_unshuffle(U):
