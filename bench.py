@@ -246,12 +246,13 @@ def main():
                     "probe": "events around every conv/wgrad launch of the first timed step",
                     "conv_time_share_of_probed_step": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4)}
             if "wino" in name:
-                # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2*N*OH*OW*Cout*Cin*9).  The Winograd F(2,3)-along-W
-                # kernel issues 12 instead of 18 multiply-adds per output pair, i.e. 2/3 of them reach the matrix pipe, which is
-                # why `frac` may exceed 1: the pipe itself runs at executed = 2/3 * achieved.
-                roof["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
-                roof["executed_frac"] = round(ach * 2.0 / 3.0 / F32_MFMA_PEAK_TFLOPS, 4)
-                roof["note"] = ("Winograd F(2,3) along W: 2/3 of the algorithmic multiply-adds are executed on the fp32 MFMA pipe; "
+                # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2*N*OH*OW*Cout*Cin*9).  The Winograd kernels issue
+                # fewer multiply-adds -- F(2,3) along W: 4 instead of 6 per output pair (2/3), F(4,3): 6 instead of 12 per output
+                # quad (1/2) -- which is why `frac` may exceed 1: the matrix pipe itself runs at executed = factor * achieved.
+                fac, what = (0.5, "F(4,3)") if "wino4" in name else (2.0 / 3.0, "F(2,3)")
+                roof["executed_tflops"] = round(ach * fac, 2)
+                roof["executed_frac"] = round(ach * fac / F32_MFMA_PEAK_TFLOPS, 4)
+                roof["note"] = (f"Winograd {what} along W: {fac:.3f} of the algorithmic multiply-adds are executed on the fp32 MFMA pipe; "
                                 "achieved/frac are algorithmic (can exceed the pipe's peak), executed_* is what the pipe sustains")
         cpu = None
         if not args.no_cpu_baseline and world == 1:

@@ -17,7 +17,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
-    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
+    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
@@ -82,6 +82,8 @@ def lib():
         L.srk_packed_floats.argtypes = [C.c_int, C.c_int]
         L.srk_packed_floats_wino.restype = C.c_size_t
         L.srk_packed_floats_wino.argtypes = [C.c_int, C.c_int]
+        L.srk_packed_floats_wino4.restype = C.c_size_t
+        L.srk_packed_floats_wino4.argtypes = [C.c_int, C.c_int]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), _fp]
         L.srk_conv3x3_wgrad_workspace.argtypes = [C.POINTER(WgradArgs), C.POINTER(C.c_size_t)]
@@ -182,6 +184,8 @@ def _conv_kernel_name(a) -> str:
         return f"conv3x3_bf16x3_kernel<{a.in_mode}, {3 if a.wp_format == 1 else 1}>"
     if a.wp_format == 3:
         return f"conv3x3_f32_wino_kernel<{a.in_mode}>"
+    if a.wp_format == 5:
+        return f"conv3x3_f32_wino4_kernel<{a.in_mode}>"
     vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
     bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
     mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
@@ -310,6 +314,8 @@ def loss_workspace(device) -> torch.Tensor:
 
 def packed_floats(K: int, M: int, fmt: int = 0) -> int:
     """floats of the packed buffer for a (K inputs, M outputs) conv; fmt 3 (Winograd) carries 12 taps instead of 9."""
+    if fmt == 5:
+        return lib().srk_packed_floats_wino4(K, M)
     return lib().srk_packed_floats_wino(K, M) if fmt == 3 else lib().srk_packed_floats(K, M)
 
 
@@ -323,7 +329,7 @@ class PackTable:
 
     def __init__(self, device, fmt=0):
         self.device = device
-        self.fmt = fmt               # 0: fp32 fragments, 1: split-bf16, 3: Winograd fp32 fragments (one table = one format)
+        self.fmt = fmt               # 0: fp32 fragments, 1: split-bf16, 3 / 5: Winograd F(2,3) / F(4,3) fp32 fragments
         self.entries = []
         self._dev = None
         self._total = 0

@@ -679,6 +679,196 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
   SRK_STAMP_AT(4);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(4,3) along W ("wino4", wp_format 5): four output columns from six products per kernel row (direct: 12,
+// F(2,3): 8), i.e. half the MFMAs of the direct kernel.  Transforms (Lavin & Gray):
+//   v = B^T d :  v0 = 4d0-5d2+d4, v1 = (d3+d4)-4(d1+d2), v2 = (d4-d3)+4(d1-d2), v3 = (d4-d2)+2(d3-d1), v4 = (d4-d2)-2(d3-d1),
+//                v5 = 4d1-5d3+d5
+//   u = G w   :  w0/4, -(w0+w1+w2)/6, -(w0-w1+w2)/6, w0/24+w1/12+w2/6, w0/24-w1/12+w2/6, w2      (in the weight packing)
+//   y = A^T m :  y0 = m0+m1+m2+m3+m4, y1 = (m1-m2)+2(m3-m4), y2 = (m1+m2)+4(m3+m4), y3 = (m1-m2)+8(m3-m4)+m5
+// fp32 throughout; the larger constants cost about 1.5 decimal digits against the direct kernel (2e-6 vs 1e-7 relative on
+// a K = 2000 dot product), still 2-3 orders inside the 1e-4 / 1e-3 parity bars.
+// Workgroup tile 32 rows x 16 columns x 64 channels, 8 waves = 4 row groups x 2 channel halves, six 32x32 accumulators per
+// wave; an M tile is 8 rows x 4 column quads, mapped so that the output transform is again a pure register renaming into
+// conv_epilogue's layout (source register 4q+s -> tile q, registers 4s..4s+3).  No loader wave: 8 waves x 2 per SIMD leave
+// 256 VGPRs each, and the 56 KB per 8-channel chunk (34x18 halo + 18 weight slices) go global -> LDS by DMA from the MFMA
+// waves themselves (7 instructions per wave and chunk), double-buffered, one barrier per chunk.  Needs in_slope == 1
+// (the DMA cannot apply the input LeakyReLU).
+template <int MODE>
+__global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_args a) {
+  constexpr int BN = 64, TH = 32, IH = TH + 2, IW = SRK_TW + 2;
+  constexpr int NX4 = IH * IW * 2;                 // 1224 float4: [halo pixel][k-half]
+  constexpr int NW4 = 36 * BN;                     // 18 taps x 2 k-halves x BN
+  constexpr int BUF4 = NX4 + NW4;                  // 3528 float4 = 56,448 B
+  constexpr int NINST = (BUF4 + 63) / 64;          // 56 wave-wide DMA instructions per chunk (the last one partial)
+  constexpr int NPW = (NINST + 7) / 8;             // per wave
+  __shared__ float4 smem[2 * BUF4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * TH, ow0 = tx * SRK_TW, n0 = blockIdx.y * BN;
+  const int CoutP = (a.Cout + 31) & ~31;
+  const int nq = (a.Cin + 7) >> 3;
+
+  // ---- DMA plan: instruction i = wv + 8*j moves float4 pieces [64 i, 64 i + 64) of the chunk buffer
+  constexpr unsigned OOB = 0x80000000u;
+  const int Cps_in = a.Cin >> 2;
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const float* ximg = a.x + (long)n * img_elems;
+  const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
+  const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  unsigned vo[NPW];
+  {
+    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int idx = (wv + 8 * j) * 64 + lane;
+      unsigned v = OOB;
+      if (idx < NX4) {
+        const int hp = idx >> 1, half = idx & 1;
+        const int hy = hp / IW, hx = hp - hy * IW;
+        const int ih = ih0 + hy, iw = iw0 + hx;
+        long off;
+        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 4 * half;
+        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 4 * half;
+        if (ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) v = (unsigned)(off * 4);
+      } else if (idx < BUF4) {
+        const int wi = idx - NX4;
+        const int th = wi / BN, co = wi - th * BN;
+        if (n0 + co < CoutP) v = (unsigned)((th * CoutP + n0 + co) * 16);
+      }
+      vo[j] = v;
+    }
+  }
+  // A DMA instruction is either all-halo, all-weights or the one that straddles NX4 (1224 = 19*64 + 8): the straddling
+  // one is issued twice with complementary lane masks (once per descriptor).  piece(q, b, j) = this wave's j-th
+  // instruction of chunk q into buffer b; the pieces are SPREAD over the MFMA stream (a burst of 7 right after the
+  // barrier would idle the matrix pipe: both waves of a SIMD leave the barrier together).
+  auto piece = [&](int q, int b, int j) {
+    const int i = wv + 8 * j;
+    if (q >= nq || i >= NINST) return;
+    unsigned xso = (unsigned)(8 * q * 4);
+    if (MODE == SRK_IN_UNSHUFFLE) {
+      const int c8 = 8 * q;
+      const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+      xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+    }
+    const unsigned wso = (unsigned)(q * 36 * CoutP * 16);
+    float4* dst = smem + b * BUF4 + i * 64;
+    const int idx = i * 64 + lane;
+    if (i * 64 + 64 <= NX4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], xso, 0, 0);
+    } else if (i * 64 >= NX4) {
+      if (idx < BUF4) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], wso, 0, 0);
+    } else {
+      if (idx < NX4) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], xso, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], wso, 0, 0);
+    }
+  };
+  static_assert(NPW == 7, "piece schedule below assumes 7 DMA instructions per wave and chunk");
+
+  // ---- MFMA role
+  const int wg = wv & 3, nh = wv >> 2;             // row group, output-channel half
+  f32x16 acc[6];
+#pragma unroll
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  // M index i = l32 -> column quad tcol = ((i>>2)&1) + 2*(i&1), row = 8*(i>>3) + 2*wg + ((i>>1)&1)
+  const int tcol = ((l32 >> 2) & 1) + 2 * (l32 & 1);
+  const int trow = 8 * (l32 >> 3) + 2 * wg + ((l32 >> 1) & 1);
+  const int abase = (trow * IW + 4 * tcol) * 2 + hl;
+  const int wbase = NX4 + hl * BN + 32 * nh + l32;
+  f32x4 dn[6], V[2][6], Bv[2][6];
+  auto ld_row = [&](int b, int r, int par) {
+    const f32x4* xb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + abase + r * IW * 2;
+    const f32x4* wb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + wbase + (6 * r) * 2 * BN;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dn[j] = xb[2 * j];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) Bv[par][p] = wb[p * 2 * BN];
+  };
+  auto transform = [&](int par) {
+    const f32x4 t1 = dn[1] + dn[2], t2 = dn[4] + dn[3], t3 = dn[1] - dn[2], t4 = dn[4] - dn[3];
+    const f32x4 t5 = dn[4] - dn[2], t6 = dn[3] - dn[1];
+    V[par][0] = 4.f * dn[0] - 5.f * dn[2] + dn[4];
+    V[par][1] = t2 - 4.f * t1;
+    V[par][2] = t4 + 4.f * t3;
+    V[par][3] = t5 + 2.f * t6;
+    V[par][4] = t5 - 2.f * t6;
+    V[par][5] = 4.f * dn[1] - 5.f * dn[3] + dn[5];
+  };
+  // 24 MFMAs of one kernel row; DMA pieces [j0, j0 + nj) of chunk dq into buffer db are issued between the k-step groups
+  auto mfma_row = [&](int par, int dq, int db, int j0, int nj) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[par][p][e], Bv[par][p][e], acc[p], 0, 0, 0);
+      if (e < nj) { __builtin_amdgcn_sched_barrier(0); piece(dq, db, j0 + e); __builtin_amdgcn_sched_barrier(0); }
+    }
+  };
+  // chunk q sits in buffer b.  Chunk q+1 streams into b^1: its pieces 0-1 were issued behind the previous chunk's last
+  // row, 2-6 go behind rows 0 and 1 here; after the barrier b is free and chunk q+2's pieces 0-1 go behind row 2.
+  auto chunk = [&](int q, auto P0c) {
+    constexpr int P0 = decltype(P0c)::value;
+    const int b = q & 1;
+    const bool more = q + 1 < nq;
+    ld_row(b, 1, P0 ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(P0, q + 1, b ^ 1, 2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    transform(P0 ^ 1);
+    ld_row(b, 2, P0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(P0 ^ 1, q + 1, b ^ 1, 4, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    transform(P0);
+    __syncthreads();                             // buffer b consumed (row 2 in registers); chunk q+1 landed in b^1
+    if (more) ld_row(b ^ 1, 0, P0 ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(P0, q + 2, b, 0, 2);                // tap row 2
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) transform(P0 ^ 1);
+  };
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) piece(0, 0, j);
+  piece(1, 1, 0);
+  piece(1, 1, 1);
+  __syncthreads();
+  ld_row(0, 0, 0);
+  transform(0);
+  int q = 0;
+  for (; q + 1 < nq; q += 2) {
+    chunk(q, std::integral_constant<int, 0>{});
+    chunk(q + 1, std::integral_constant<int, 1>{});
+  }
+  if (q < nq) chunk(q, std::integral_constant<int, 0>{});
+  // output transform: source register 4q+s -> epilogue tile q, registers 4s .. 4s+3 (columns 4*tcol .. +3)
+  f32x16 out[4][1];
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+      const int src = 4 * tq + sx;
+      const float m0 = acc[0][src], m1 = acc[1][src], m2 = acc[2][src], m3 = acc[3][src], m4 = acc[4][src], m5 = acc[5][src];
+      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+      out[tq][0][4 * sx + 0] = (m0 + s12) + s34;
+      out[tq][0][4 * sx + 1] = d12 + 2.f * d34;
+      out[tq][0][4 * sx + 2] = s12 + 4.f * s34;
+      out[tq][0][4 * sx + 3] = (d12 + 8.f * d34) + m5;
+    }
+  conv_epilogue<32, 4>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
+}
+
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
 int launch_k(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * MT);
@@ -697,6 +887,15 @@ int launch_wino(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * 2);
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
   hipLaunchKernelGGL((conv3x3_f32_wino_kernel<MODE>), grid, dim3(576), 0, st, a);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
+template <int MODE>
+int launch_wino4(const srk_conv_args& a, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, 32);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+  hipLaunchKernelGGL((conv3x3_f32_wino4_kernel<MODE>), grid, dim3(512), 0, st, a);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
@@ -752,6 +951,15 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
     if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
     return srk_launch_conv_bf16x3(a, st);
+  }
+  if (a.wp_format == 5) {
+    // Winograd F(4,3)-along-W fragments (fmt 5): as format 3, plus no input activation (staged by DMA)
+    if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
+    if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cout % 64) || (a.Cin % 8) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+    if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 8))) return SRK_ERR_UNSUPPORTED;
+    if ((a.x_ldc % 4) || (a.x_coff % 4) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
+    if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
+    return a.in_mode == SRK_IN_PLAIN ? launch_wino4<SRK_IN_PLAIN>(a, st) : launch_wino4<SRK_IN_UNSHUFFLE>(a, st);
   }
   if (a.wp_format == 3) {
     // Winograd F(2,3)-along-W fragments (srk_pack_weights with fmt 3): stride 1, 8-channel chunks, 64-channel output tiles

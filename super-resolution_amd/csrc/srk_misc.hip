@@ -13,7 +13,7 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
   const int h = (int)(t & 1); t >>= 1;
-  const int ntap = e.fmt == 3 ? 12 : 9;
+  const int ntap = e.fmt == 3 ? 12 : (e.fmt == 5 ? 18 : 9);
   const int tap = (int)(t % ntap); t /= ntap;
   const int ql = (int)t;                      // chunk index relative to k_off/8
   const int q = (e.k_off >> 3) + ql;
@@ -35,7 +35,19 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
         if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
         w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
       }
-      if (e.fmt == 3) {
+      if (e.fmt == 5) {
+        // F(4,3): 18 taps = 3 kernel rows x 6 positions, u = G w
+        const int r = tap / 6, p = tap - 6 * r;
+        float w0, w1, w2;
+        if (!e.transpose) { w0 = w9[3 * r]; w1 = w9[3 * r + 1]; w2 = w9[3 * r + 2]; }
+        else { w0 = w9[8 - 3 * r]; w1 = w9[7 - 3 * r]; w2 = w9[6 - 3 * r]; }
+        val = p == 0 ? 0.25f * w0
+            : p == 1 ? (-1.f / 6.f) * ((w0 + w1) + w2)
+            : p == 2 ? (-1.f / 6.f) * ((w0 - w1) + w2)
+            : p == 3 ? (w0 * (1.f / 24.f) + w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
+            : p == 4 ? (w0 * (1.f / 24.f) - w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
+            : w2;
+      } else if (e.fmt == 3) {
         const int r = tap >> 2, p = tap & 3;
         float w0, w1, w2;
         if (!e.transpose) { w0 = w9[3 * r]; w1 = w9[3 * r + 1]; w2 = w9[3 * r + 2]; }
@@ -173,13 +185,17 @@ extern "C" size_t srk_packed_floats_wino(int K, int M) {
   return (size_t)srk_div_up(K, 16) * 2 * 12 * 2 * srk_round_up(M, 32) * 4;
 }
 
+extern "C" size_t srk_packed_floats_wino4(int K, int M) {
+  return (size_t)srk_div_up(K, 16) * 2 * 18 * 2 * srk_round_up(M, 32) * 4;
+}
+
 extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   if (!e || !total || n <= 0) return SRK_ERR_BAD_ARG;
   int64_t acc = 0;
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
-    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5)) return SRK_ERR_BAD_ARG;
     if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
     e[i].elem_begin = acc;
     // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
@@ -187,7 +203,7 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
     int k_end = e[i].k_off + e[i].k_len;
     int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
     // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
-    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : 9) * 2 * srk_round_up(e[i].M, 32);
+    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : 9)) * 2 * srk_round_up(e[i].M, 32);
   }
   *total = acc;
   return SRK_OK;

@@ -163,13 +163,14 @@ class GeneratorEngine:
             ps += [m.weight, m.bias]
         return ps
 
-    def _build_tables(self, device):
+    def _build_tables(self, device, geo):
         g = self.gen
+        gN, gH, gW = geo                      # LR input extent of the forward that triggered the build
         F_, C_ = g.filters, g.channels
         self.flat_f, self.flat_b = _Flat(), _Flat()
         # one table per (direction, fragment format)
-        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3)}
-        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3)}
+        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3, 5)}
+        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3, 5)}
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
         bf = self.precision in ("bf16x3", "bf16")
@@ -178,38 +179,49 @@ class GeneratorEngine:
         # exact-fp32 mode: stride-1 convs with 64-multiple outputs run the Winograd F(2,3)-along-W kernel (2/3 of the MFMAs)
         wino = (not bf) and os.environ.get("SRK_WINOGRAD", "1") != "0"
 
-        def fmt_of(K, M):
+        wino4 = wino and os.environ.get("SRK_WINOGRAD4", "1") != "0"
+
+        def fmt_of(K, M, up=1):
+            """fragment format of a conv with K inputs, M outputs running at `up` x the LR resolution"""
             if bf:
                 return 1 if (K % 16 == 0 and M >= 16) else 0
-            return 3 if (wino and L.wino_eligible(K, M)) else 0
+            if not (wino and L.wino_eligible(K, M)):
+                return 0
+            # F(4,3) works on 32 x 16 tiles, one 8-wave workgroup per CU: worth it when those tiles fill the chip and do not
+            # pad the image more than the 16 x 16 tiles of the F(2,3) kernel would
+            h, w = gH * up, gW * up
+            wgs = gN * ((h + 31) // 32) * ((w + 15) // 16) * (M // 64)
+            if wino4 and wgs >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16:
+                return 5
+            return 3
 
-        def simple(name, conv, ps=False, need_bwd=True):
+        def simple(name, conv, ps=False, need_bwd=True, up=1):
             co, ci = conv.weight.shape[:2]
-            ff = fmt_of(ci, co) if (not ps or (co // 4) % 4 == 0) else 0
+            ff = fmt_of(ci, co, up) if (not ps or (co // 4) % 4 == 0) else 0
             fi = self.flat_f.reserve(L.packed_floats(ci, co, ff))
             self.fmt_f[fi] = ff
             jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=ci, ps=ps)))
             bi = None
             if need_bwd:
-                fb = fmt_of(co, ci) if (not ps or (co // 4) % 16 == 0) else 0
-                if fb == 3 and conv.stride[0] != 1:
+                fb = fmt_of(co, ci, up) if (not ps or (co // 4) % 16 == 0) else 0
+                if fb in (3, 5) and conv.stride[0] != 1:
                     fb = 0
                 bi = self.flat_b.reserve(L.packed_floats(co, ci, fb))
                 self.fmt_b[bi] = fb
                 jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=co, transpose=True, ps=ps)))
             return fi, bi
 
-        def drb(d, s5):
+        def drb(d, s5, up=1):
             p = DrbPack(F_)
             for k in range(1, 6):
                 w = getattr(d, f"b{k}")[0].weight
-                ff = fmt_of(k * F_, F_)
+                ff = fmt_of(k * F_, F_, up)
                 p.fwd[k] = self.flat_f.reserve(L.packed_floats(k * F_, F_, ff))
                 self.fmt_f[p.fwd[k]] = ff
                 jobs_f.append((w, p.fwd[k], dict(M=F_, k_off=0, k_len=k * F_, K_total=k * F_)))
             for m in range(0, 5):
                 K = (5 - m) * F_
-                fb = fmt_of(K, F_) if (F_ % 16 == 0 or not bf) else 0
+                fb = fmt_of(K, F_, up) if (F_ % 16 == 0 or not bf) else 0
                 p.bwd[m] = self.flat_b.reserve(L.packed_floats(K, F_, fb))
                 self.fmt_b[p.bwd[m]] = fb
                 for k in range(5, m, -1):     # input slice (5-k) of the dy buffer carries dy_k
@@ -226,13 +238,14 @@ class GeneratorEngine:
             self.drbs.append([drb(d, INNER_RES_SCALE * (rr.res_scale if j == 2 else 1.0)) for j, d in enumerate(rr.dense_blocks)])
         self.idx["conv2"] = simple("conv2", g.conv2)
         for u in range(g.num_upsample):
-            self.idx[f"up{u}"] = simple(f"up{u}", g.upsampling[3 * u], ps=True)
+            self.idx[f"up{u}"] = simple(f"up{u}", g.upsampling[3 * u], ps=True, up=2 ** u)
+        hr_up = 2 ** g.num_upsample
         self.drbs_final = []
         if g.num_final_layer_res > 0:
             for rr in g.res_blocks_final:
-                self.drbs_final.append([drb(d, INNER_RES_SCALE * (rr.res_scale if j == 2 else 1.0)) for j, d in enumerate(rr.dense_blocks)])
-        self.idx["conv3.0"] = simple("conv3.0", g.conv3[0])
-        self.idx["conv3.2"] = simple("conv3.2", g.conv3[2])
+                self.drbs_final.append([drb(d, INNER_RES_SCALE * (rr.res_scale if j == 2 else 1.0), up=hr_up) for j, d in enumerate(rr.dense_blocks)])
+        self.idx["conv3.0"] = simple("conv3.0", g.conv3[0], up=hr_up)
+        self.idx["conv3.2"] = simple("conv3.2", g.conv3[2], up=hr_up)
 
         self.flat_f.materialize(device)
         self.flat_b.materialize(device)
@@ -243,15 +256,27 @@ class GeneratorEngine:
         for t in list(self.tab_f.values()) + list(self.tab_b.values()):
             t.finalize()
 
-    def _ensure_packed(self, need_bwd: bool):
+    def _wino4_levels(self, geo):
+        """which resolution levels (1x, 2x, ... of the LR extent) run the F(4,3) kernel for a 64-output conv"""
+        gN, gH, gW = geo
+        out = []
+        for u in range(self.gen.num_upsample + 1):
+            h, w = gH * 2 ** u, gW * 2 ** u
+            out.append(gN * ((h + 31) // 32) * ((w + 15) // 16) >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16)
+        return tuple(out)
+
+    def _ensure_packed(self, need_bwd: bool, geo=None):
         """(Re)pack the weights.  The canonical OIHW Parameters stay the source of truth (optimizer steps,
         load_state_dict, weight_reset all write them); packing is one kernel launch over the whole table, so it
         is simply redone on every forward (fwd table) / backward (bwd table) instead of tracking versions."""
         ps = self.params()
         dev = ps[0].device
-        sig = (dev, self.precision, tuple(p.data_ptr() for p in ps))
+        geo = geo or getattr(self, "_geo", (1, 16, 16))
+        self._geo = geo
+        # the tables depend on the geometry only through the F(4,3)-vs-F(2,3) decision per resolution level
+        sig = (dev, self.precision, self._wino4_levels(geo), tuple(p.data_ptr() for p in ps))
         if sig != self._sig:
-            self._build_tables(dev)
+            self._build_tables(dev, geo)
             self._sig = sig
         if need_bwd:
             for t in self.tab_b.values():
@@ -399,8 +424,8 @@ class GeneratorEngine:
         if not x.is_cuda:
             raise RuntimeError("super-resolution_amd: the generator hot path only runs on a ROCm GPU tensor "
                                "(no CPU fallback; use oracle/ for a CPU check in tests)")
-        self._ensure_packed(need_bwd=False)
         N, C_, H, W = x.shape
+        self._ensure_packed(need_bwd=False, geo=(N, H, W))
         assert C_ == g.channels
         F_ = g.filters
         dev = x.device
@@ -470,8 +495,8 @@ class GeneratorEngine:
     def backward(self, saved, g_out: torch.Tensor, need_input_grad: bool):
         """g_out: NCHW gradient of the raw conv3 output.  Returns (dx NCHW or None, {param: grad})."""
         g = self.gen
-        self._ensure_packed(need_bwd=True)
         N, H, W = saved["geo"]
+        self._ensure_packed(need_bwd=True, geo=(N, H, W))
         h, w = saved["hr"]
         F_, C_ = g.filters, g.channels
         dev = g_out.device

@@ -457,19 +457,21 @@ def test_flat_workspace_and_errors(U):
 # Winograd F(2,3)-along-W kernel (wp_format 3): same fused conv, 2/3 of the MFMAs; fp32 throughout
 @pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 64, 64, 2), (320, 64, 16, 16, 1), (8, 64, 9, 7, 2), (64, 128, 33, 17, 1),
                                          (128, 64, 20, 40, 1), (16, 64, 5, 3, 1), (64, 64, 1, 1, 1), (24, 192, 16, 31, 2)])
-def test_wino_conv_fwd(U, ci, co, h, w, n):
+@pytest.mark.parametrize("fmt", [3, 5])
+def test_wino_conv_fwd(U, ci, co, h, w, n, fmt):
     L = U.L
     x = _rand((n, ci, h, w), 71)
     wt = _rand((co, ci, 3, 3), 72, 1.0 / np.sqrt(9 * ci))
     b = _rand((co,), 73, 0.1)
     ref = O.lrelu(O.conv3x3(x, wt, b), 0.01)
-    wp, _ = U.pack_fwd(wt, fmt=3)
+    wp, _ = U.pack_fwd(wt, fmt=fmt)
     y = torch.full((n, h, w, co), float("nan"), device="cuda")
-    L.conv3x3(L.View(U.nhwc(x)), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01, wp_format=3)
+    L.conv3x3(L.View(U.nhwc(x)), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01, wp_format=fmt)
     assert U.rel_err(U.nchw(y), ref) < TOL
 
 
-def test_wino_slices_residuals_mask_and_dgrad(U):
+@pytest.mark.parametrize("fmt", [3, 5])
+def test_wino_slices_residuals_mask_and_dgrad(U, fmt):
     """the dense-block addressing (channel prefix in, channel slice out, two residuals, alpha, LeakyReLU' mask) and the
     data gradient (transposed, tap-flipped weights through the same transform) on the Winograd kernel."""
     L = U.L
@@ -482,9 +484,9 @@ def test_wino_slices_residuals_mask_and_dgrad(U):
     ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
     buf = U.nhwc(xfull)
     out = torch.zeros(n, h, w, 2 * F_, device="cuda")
-    wp, _ = U.pack_fwd(wt, fmt=3)
+    wp, _ = U.pack_fwd(wt, fmt=fmt)
     L.conv3x3(L.View(buf, F_, 3 * F_), wp, b.cuda(), L.View(out, F_, F_), N=n, H=h, W=w, OH=h, OW=w, Cin=3 * F_, Cout=F_, alpha=0.2,
-              r1=L.View(U.nhwc(r1)), beta1=0.5, r2=L.View(U.nhwc(r2)), beta2=1.0, mask=L.View(U.nhwc(m)), mask_slope=0.01, wp_format=3)
+              r1=L.View(U.nhwc(r1)), beta1=0.5, r2=L.View(U.nhwc(r2)), beta2=1.0, mask=L.View(U.nhwc(m)), mask_slope=0.01, wp_format=fmt)
     assert U.rel_err(U.nchw(out, F_, F_), ref) < TOL
     assert out[..., :F_].abs().max().item() == 0
     # data gradient: dx = conv(dy, flip(W)^T)
@@ -493,30 +495,31 @@ def test_wino_slices_residuals_mask_and_dgrad(U):
     y = O.conv3x3(x, w2, None)
     g = _rand(y.shape, 82)
     y.backward(g)
-    wpb, _ = U.pack_bwd(w2, fmt=3)
+    wpb, _ = U.pack_bwd(w2, fmt=fmt)
     dx = torch.full((n, h, w, F_), float("nan"), device="cuda")
-    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=2 * F_, Cout=F_, wp_format=3)
+    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=2 * F_, Cout=F_, wp_format=fmt)
     assert U.rel_err(U.nchw(dx), x.grad) < TOL
 
 
-def test_wino_pixel_shuffle_fold_and_unshuffle(U):
+@pytest.mark.parametrize("fmt", [3, 5])
+def test_wino_pixel_shuffle_fold_and_unshuffle(U, fmt):
     L = U.L
     n, F_, h, w = 2, 64, 8, 12
     x = _rand((n, F_, h, w), 83).requires_grad_(True)
     wt = _rand((4 * F_, F_, 3, 3), 84, 0.04)
     b = _rand((4 * F_,), 85, 0.1)
     y = O.pixel_shuffle(O.lrelu(O.conv3x3(x, wt, b), 0.01), 2)
-    wp, _ = U.pack_fwd(wt, ps=True, fmt=3)
+    wp, _ = U.pack_fwd(wt, ps=True, fmt=fmt)
     bp = b.view(-1, 4).t().contiguous().view(-1).cuda()
     out = torch.full((n, 2 * h, 2 * w, F_), float("nan"), device="cuda")
-    L.conv3x3(L.View(U.nhwc(x.detach())), wp, bp, L.View(out), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, slope=0.01, ps_out=True, wp_format=3)
+    L.conv3x3(L.View(U.nhwc(x.detach())), wp, bp, L.View(out), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, slope=0.01, ps_out=True, wp_format=fmt)
     assert U.rel_err(U.nchw(out), y.detach()) < TOL
     g = _rand(y.shape, 86)
     y2 = O.pixel_shuffle(O.conv3x3(x, wt, None), 2)
     y2.backward(g)
-    wpb, _ = U.pack_bwd(wt, ps=True, fmt=3)
+    wpb, _ = U.pack_bwd(wt, ps=True, fmt=fmt)
     dx = torch.full((n, h, w, F_), float("nan"), device="cuda")
-    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=4 * F_, Cout=F_, in_mode=L.IN_UNSHUFFLE, wp_format=3)
+    L.conv3x3(L.View(U.nhwc(g)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=4 * F_, Cout=F_, in_mode=L.IN_UNSHUFFLE, wp_format=fmt)
     assert U.rel_err(U.nchw(dx), x.grad) < TOL
 
 

@@ -3,7 +3,8 @@ the CPU oracle is too slow to be the checker for every case:
   * adjointness  <conv(x), y> == <x, conv^T(y)>  and  <dW, V> == <dy, conv_V(x)>  (data-/weight-gradient kernels vs the
     forward kernel, no oracle needed),
   * linearity of the un-activated convolution,
-  * batch independence of the generator (image i does not depend on the other images; bit-exact),
+  * batch independence of the generator (image i does not depend on the other images or its slot; bit-exact at equal
+    batch size, 1e-5 across batch sizes where another kernel variant may be selected),
   * run-to-run determinism of forward + backward (all 702 gradient tensors bit-identical),
   * plus one direct oracle comparison of the full-depth generator on 2 images (a few seconds of CPU).
 Both the exact-fp32 kernels and the opt-in split-bf16 kernels are exercised.
@@ -98,9 +99,13 @@ def test_full_generator_properties(full_generator, mode):
     lr, hr = lr.cuda(), hr.cuda()
     with torch.no_grad():
         y = gen(lr)
-        y1 = gen(lr[1:2])
         assert torch.isfinite(y).all()
-        assert torch.equal(y1, y[1:2])          # image 1 alone == image 1 inside the batch
+        # image 1 in another slot, among other neighbours (same batch size: the kernel selection -- F(4,3) / F(2,3) /
+        # direct -- depends on how many tiles the batch offers, and the variants differ at the 1e-6 level)
+        y2 = gen(lr[[1, 0, 3, 3]])
+        assert torch.equal(y2[0], y[1]) and torch.equal(y2[1], y[0]) and torch.equal(y2[2], y[3])
+        y1 = gen(lr[1:2])                       # alone: same image, possibly another kernel variant
+        assert ((y1 - y[1:2]).abs().max() / y.abs().max()).item() < 1e-5
     grads = []
     for _ in range(2):
         gen.zero_grad(set_to_none=True)

@@ -16,7 +16,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     N, H, W, F = int(os.environ.get("N", 16)), 64, 64, 64
-    FMT = int(os.environ.get("FMT", 0))          # 0: direct fp32 kernel, 3: Winograd F(2,3)-along-W kernel
+    FMT = int(os.environ.get("FMT", 0))          # 0: direct fp32 kernel, 3 / 5: Winograd F(2,3) / F(4,3) along W
     dev = "cuda"
     buf = torch.randn(N, H, W, 5 * F, device=dev)
     out = torch.empty(N, H, W, F, device=dev)
