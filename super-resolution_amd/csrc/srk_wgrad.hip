@@ -347,47 +347,64 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
   int dyc, dyij = 0;
   if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
   const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
-  // stage tile `tile` into buffer `b`: wave w issues instructions w, w+8, ...
-  auto stage = [&](int tile, int b) {
+  // Tile `tile` goes into buffer `b` as NINST wave-wide DMA instructions; wave w owns instructions w, w+8, ... (5 or 6).
+  // They are issued ONE AT A TIME between the k-steps of the tile being computed (a burst right after the barrier would
+  // idle the matrix pipe: both waves of a SIMD leave the barrier together).
+  constexpr int NPW = (NINST + 7) / 8;
+  struct TileCtx { int oh0, ow0; __amdgpu_buffer_rsrc_t xr, dr; };
+  auto tile_ctx = [&](int tile) {
     int tt = tile;
     const int tx = tt % B.tilesW; tt /= B.tilesW;
     const int ty = tt % B.tilesH; tt /= B.tilesH;
     const int n = tt;
-    const int oh0 = ty * G::TH, ow0 = tx * WTW;
-    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
+    TileCtx c;
+    c.oh0 = ty * G::TH; c.ow0 = tx * WTW;
+    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
+    return c;
+  };
+  auto piece = [&](const TileCtx& c, int b, int j) {
+    const int i = j * 8 + wv;                                      // wave-uniform instruction index
+    if (i >= NINST) return;
     float* buf = smem + b * WW_TILE_FLOATS;
-#pragma unroll
-    for (int i0 = 0; i0 < (NINST + 7) / 8; ++i0) {
-      const int i = i0 * 8 + wv;                                   // wave-uniform instruction index
-      if (i >= NINST) break;
-      if (i < G::TP * 16 / 64) {
-        const int oh = oh0 + (i >> 2), ow = ow0 + 4 * (i & 3) + lp; // pixel 4i + lp of the 4 x 16 tile
-        unsigned off;
-        if (DYMODE == SRK_IN_UNSHUFFLE) off = (unsigned)((((2 * oh + (dyij >> 1)) * (2 * B.OW) + 2 * ow + (dyij & 1)) * a.dy_ldc + dyc) * 4);
-        else off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + dyc) * 4);
-        const bool ok = oh < B.OH && ow < B.OW && co_ok;
-        wdma16(dr, buf + i * 256, ok ? off : W_OOB);
-      } else {
-        const int hp = 4 * (i - G::TP * 16 / 64) + lp;            // halo pixel 0..107
-        const int hy = hp / G::IW, hx = hp - hy * G::IW;
-        const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-        const bool ok = ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci_ok;
-        const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
-        wdma16(xr, buf + i * 256, ok ? off : W_OOB);
-      }
+    if (i < G::TP * 16 / 64) {
+      const int oh = c.oh0 + (i >> 2), ow = c.ow0 + 4 * (i & 3) + lp;   // pixel 4i + lp of the 4 x 16 tile
+      unsigned off;
+      if (DYMODE == SRK_IN_UNSHUFFLE) off = (unsigned)((((2 * oh + (dyij >> 1)) * (2 * B.OW) + 2 * ow + (dyij & 1)) * a.dy_ldc + dyc) * 4);
+      else off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + dyc) * 4);
+      const bool ok = oh < B.OH && ow < B.OW && co_ok;
+      wdma16(c.dr, buf + i * 256, ok ? off : W_OOB);
+    } else {
+      const int hp = 4 * (i - G::TP * 16 / 64) + lp;              // halo pixel 0..107
+      const int hy = hp / G::IW, hx = hp - hy * G::IW;
+      const int ih = c.oh0 - 1 + hy, iw = c.ow0 - 1 + hx;
+      const bool ok = ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci_ok;
+      const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
+      wdma16(c.xr, buf + i * 256, ok ? off : W_OOB);
     }
   };
+  static_assert(NPW <= 8, "one DMA piece per k-step");
 
   // per-lane LDS offsets (floats) of pair (row 2ks + kk/4, column pair 2*(kk%4) + hl) for k-step kk = 0..7
   const int aoff = ((2 * ks) * 16 + 2 * hl) * 64 + 32 * wa + l32;                      // g0; g1 = + 64
   const int boff = G::TP * 64 + ((2 * ks) * G::IW + 2 * hl) * 64 + 32 * wb + l32;      // d0 of kernel row 0; d_j = + 64 j
 
-  if (t_begin < t_end) stage(t_begin, 0);
+  if (t_begin < t_end) {
+    const TileCtx c0 = tile_ctx(t_begin);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) piece(c0, 0, j);
+  }
   __syncthreads();
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int b = (tile - t_begin) & 1;
-    if (tile + 1 < t_end) stage(tile + 1, b ^ 1);
+    const bool more = tile + 1 < t_end;
+    const TileCtx cn = tile_ctx(more ? tile + 1 : tile);
+    if (!active) {
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) piece(cn, b ^ 1, j);
+      }
+    }
     if (active) {
       const float* ap = smem + b * WW_TILE_FLOATS + aoff;
       const float* bp = smem + b * WW_TILE_FLOATS + boff;
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[4 * r + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[4 * r + q], 0, 0, 0);
         }
+        if (kk < NPW && more) { __builtin_amdgcn_sched_barrier(0); piece(cn, b ^ 1, kk); __builtin_amdgcn_sched_barrier(0); }
       }
     }
     __syncthreads();               // next tile landed (vmcnt drained by the barrier's fence), this one fully read
