@@ -20,6 +20,22 @@
 // 142,144,168.
 #include "srk_internal.h"
 #include <stdlib.h>
+#include <type_traits>
+
+#ifdef SRK_STAMP
+// diagnostic build only (tools/stamp_wgrad.py): per-workgroup cycle counters of the Winograd weight-gradient kernel
+__device__ unsigned long long* g_srk_wstamps = nullptr;
+extern "C" int srk_debug_set_wstamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_srk_wstamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#define WST_DECL() unsigned long long wst_t = __builtin_amdgcn_s_memtime(), wst_sum[4] = {0, 0, 0, 0}
+#define WST(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); wst_sum[k] += t_ - wst_t; wst_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WST_END() do { if ((threadIdx.x & 63) == 0 && g_srk_wstamps) for (int k_ = 0; k_ < 4; ++k_) g_srk_wstamps[((blockIdx.x + gridDim.x * blockIdx.y) * 8 + (threadIdx.x >> 6)) * 4 + k_] = wst_sum[k_]; } while (0)
+#else
+#define WST_DECL() do { } while (0)
+#define WST(k) do { } while (0)
+#define WST_END() do { } while (0)
+#endif
 
 namespace {
 
@@ -305,7 +321,7 @@ constexpr int WW_TILE_FLOATS = WGeo<1>::TP * 64 + WGeo<1>::NHP * 64;     // 1100
 template <int DYMODE>
 __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch B, float* part, float* pbias) {
   using G = WGeo<1>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * WW_TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[3 * WW_TILE_FLOATS];     // three tile buffers (132 KB): prefetch distance 2
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform, provably so (SGPR): DMA bases, branches
   const int hl = lane >> 5, l32 = lane & 31;
@@ -389,55 +405,99 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
   const int aoff = ((2 * ks) * 16 + 2 * hl) * 64 + 32 * wa + l32;                      // g0; g1 = + 64
   const int boff = G::TP * 64 + ((2 * ks) * G::IW + 2 * hl) * 64 + 32 * wb + l32;      // d0 of kernel row 0; d_j = + 64 j
 
+  // Prefetch distance 2: the pieces of tile t+2 are issued during the k-steps of tile t, so a DMA has a whole tile time
+  // (~6 us) to land -- with distance 1 the last pieces had only a quarter of that and the closing barrier waited for them
+  // (measured: 2000 of 15600 cycles per tile).  The closing barrier therefore must NOT drain the newest DMAs: it waits for
+  // vmcnt <= (pieces issued this tile) -- the counter retires in order, so everything older (tile t+1) has landed -- and
+  // is a bare s_barrier instead of __syncthreads().
+  const int my_pieces = (NINST - wv + 7) / 8;                      // 6 for waves 0-2, 5 for the others (NINST = 43)
+  auto tile_barrier = [&](bool issued) {
+    if (!issued) __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+    else if (my_pieces == 6) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0075);                       // vmcnt(5) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+  };
   if (t_begin < t_end) {
     const TileCtx c0 = tile_ctx(t_begin);
 #pragma unroll
     for (int j = 0; j < NPW; ++j) piece(c0, 0, j);
+    if (t_begin + 1 < t_end) {
+      const TileCtx c1 = tile_ctx(t_begin + 1);
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) piece(c1, 1, j);
+    }
   }
   __syncthreads();
+  WST_DECL();
+  int b = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int b = (tile - t_begin) & 1;
-    const bool more = tile + 1 < t_end;
-    const TileCtx cn = tile_ctx(more ? tile + 1 : tile);
+    const bool more = tile + 2 < t_end;
+    const int bn = b >= 1 ? b - 1 : 2;                             // (b + 2) % 3: the buffer tile-1 used, free since its barrier
+    const TileCtx cn = tile_ctx(more ? tile + 2 : tile);
+    WST(0);                                                      // tile bookkeeping
     if (!active) {
       if (more) {
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) piece(cn, b ^ 1, j);
+        for (int j = 0; j < NPW; ++j) piece(cn, bn, j);
       }
     }
     if (active) {
       const float* ap = smem + b * WW_TILE_FLOATS + aoff;
       const float* bp = smem + b * WW_TILE_FLOATS + boff;
-      float g[2][2], d[2][3][4];
-      auto ld_k = [&](int q, int kk) {
+      // One k-step = 12 MFMAs in three kernel-row groups.  The two waves of a SIMD leave every barrier together and stay
+      // in phase, so anything a wave does between MFMA groups is a bubble of the shared matrix pipe unless it is short
+      // enough to hide behind the MFMA still executing.  Hence the non-MFMA work is cut into small pieces between the
+      // groups: raw LDS reads of the NEXT step first (they have two groups to land), the DMA piece after group 0, the
+      // operand transform of rows 0-1 after group 1 (their registers are dead by then), row 2 and the dy operands last.
+      float g[2], d[3][4], av[4], bv[3][4];
+      auto ld_k = [&](int kk) {
         const int o = ((kk >> 2) * 16 + 4 * (kk & 3)) * 64, ox = ((kk >> 2) * G::IW + 4 * (kk & 3)) * 64;
-        g[q][0] = ap[o]; g[q][1] = ap[o + 64];
+        g[0] = ap[o]; g[1] = ap[o + 64];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) d[q][r][j] = bp[ox + (r * G::IW + j) * 64];
+          for (int j = 0; j < 4; ++j) d[r][j] = bp[ox + (r * G::IW + j) * 64];
       };
-      ld_k(0, 0);
+      auto xform_row = [&](int r) {
+        bv[r][0] = d[r][0] - d[r][2]; bv[r][1] = d[r][1] + d[r][2]; bv[r][2] = d[r][2] - d[r][1]; bv[r][3] = d[r][1] - d[r][3];
+      };
+      auto xform_a = [&]() {
+        const float g0 = g[0], g1 = g[1];
+        av[0] = g0; av[1] = g0 + g1; av[2] = g0 - g1; av[3] = g1;
+        if (do_bias) bsum += g0 + g1;
+      };
+      auto mfma_row = [&](int r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * r + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[r][q], acc[4 * r + q], 0, 0, 0);
+      };
+      ld_k(0);
+      xform_row(0); xform_row(1); xform_row(2); xform_a();
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const int cur = kk & 1;
-        if (kk + 1 < 8) ld_k(cur ^ 1, kk + 1);
+        const bool nxt = kk + 1 < 8;
         __builtin_amdgcn_sched_barrier(0);
-        const float g0 = g[cur][0], g1 = g[cur][1];
-        const float av[4] = {g0, g0 + g1, g0 - g1, g1};
-        if (do_bias) bsum += g0 + g1;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const float bv[4] = {d[cur][r][0] - d[cur][r][2], d[cur][r][1] + d[cur][r][2], d[cur][r][2] - d[cur][r][1], d[cur][r][1] - d[cur][r][3]};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[4 * r + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[4 * r + q], 0, 0, 0);
-        }
-        if (kk < NPW && more) { __builtin_amdgcn_sched_barrier(0); piece(cn, b ^ 1, kk); __builtin_amdgcn_sched_barrier(0); }
+        if (nxt) ld_k(kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < NPW && more) { piece(cn, bn, kk); __builtin_amdgcn_sched_barrier(0); }
+        mfma_row(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) { xform_row(0); xform_row(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) { xform_row(2); xform_a(); }
       }
     }
-    __syncthreads();               // next tile landed (vmcnt drained by the barrier's fence), this one fully read
+    WST(1);                                                      // k-steps (issue time of this wave)
+    tile_barrier(more);            // tile+1 landed (older than this tile's DMAs), this buffer fully read
+    WST(2);                                                      // barrier wait
+    b = b == 2 ? 0 : b + 1;
   }
+  __syncthreads();
 
+  WST_END();
   // G^T: the nine tap tiles from the twelve position tiles (in place: tap 3r+s <- acc[4r..4r+3])
   f32x16 tap[9];
 #pragma unroll
