@@ -698,10 +698,11 @@ template <int MODE>
 __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_args a) {
   constexpr int BN = 64, TH = 32, IH = TH + 2, IW = SRK_TW + 2;
   constexpr int NX4 = IH * IW * 2;                 // 1224 float4: [halo pixel][k-half]
+  constexpr int NXI = (NX4 + 63) / 64;             // 20 wave-wide DMA instructions of halo (the last one: 8 live lanes)
+  constexpr int NXP = NXI * 64;                    // halo region padded to whole instructions (1280 float4)
   constexpr int NW4 = 36 * BN;                     // 18 taps x 2 k-halves x BN
-  constexpr int BUF4 = NX4 + NW4;                  // 3528 float4 = 56,448 B
-  constexpr int NINST = (BUF4 + 63) / 64;          // 56 wave-wide DMA instructions per chunk (the last one partial)
-  constexpr int NPW = (NINST + 7) / 8;             // per wave
+  constexpr int NWI = NW4 / 64;                    // 36 instructions of weights
+  constexpr int BUF4 = NXP + NW4;                  // 3584 float4 = 57,344 B
   __shared__ float4 smem[2 * BUF4];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -716,8 +717,11 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const int CoutP = (a.Cout + 31) & ~31;
   const int nq = (a.Cin + 7) >> 3;
 
-  // ---- DMA plan: instruction i = wv + 8*j moves float4 pieces [64 i, 64 i + 64) of the chunk buffer
+  // ---- DMA plan.  Per chunk 20 halo + 36 weight instructions (1 KB each).  Piece j of a wave has a COMPILE-TIME kind so
+  // that issuing it is an m0 update + one buffer_load...lds: j = 0, 1 -> halo instruction wv + 8j; j = 2 -> halo 16 + wv
+  // (waves 0-3); j = 3..6 -> weight instruction wv + 8(j-3); j = 7 -> weight 32 + wv (waves 0-3).
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int NPW = 8;
   const int Cps_in = a.Cin >> 2;
   long img_elems = (long)a.H * a.W * a.x_ldc;
   if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
@@ -730,8 +734,8 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int idx = (wv + 8 * j) * 64 + lane;
+    for (int j = 0; j < 3; ++j) {
+      const int idx = (j < 2 ? wv + 8 * j : 16 + wv) * 64 + lane;
       unsigned v = OOB;
       if (idx < NX4) {
         const int hp = idx >> 1, half = idx & 1;
@@ -741,40 +745,38 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
         if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 4 * half;
         else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 4 * half;
         if (ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) v = (unsigned)(off * 4);
-      } else if (idx < BUF4) {
-        const int wi = idx - NX4;
-        const int th = wi / BN, co = wi - th * BN;
-        if (n0 + co < CoutP) v = (unsigned)((th * CoutP + n0 + co) * 16);
       }
       vo[j] = v;
     }
-  }
-  // A DMA instruction is either all-halo, all-weights or the one that straddles NX4 (1224 = 19*64 + 8): the straddling
-  // one is issued twice with complementary lane masks (once per descriptor).  piece(q, b, j) = this wave's j-th
-  // instruction of chunk q into buffer b; the pieces are SPREAD over the MFMA stream (a burst of 7 right after the
-  // barrier would idle the matrix pipe: both waves of a SIMD leave the barrier together).
-  auto piece = [&](int q, int b, int j) {
-    const int i = wv + 8 * j;
-    if (q >= nq || i >= NINST) return;
-    unsigned xso = (unsigned)(8 * q * 4);
-    if (MODE == SRK_IN_UNSHUFFLE) {
-      const int c8 = 8 * q;
-      const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
-      xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+#pragma unroll
+    for (int j = 3; j < NPW; ++j) {
+      const int wi = (j < 7 ? wv + 8 * (j - 3) : 32 + wv) * 64 + lane;
+      const int th = wi / BN, co = wi - th * BN;
+      vo[j] = (wi < NW4 && n0 + co < CoutP) ? (unsigned)((th * CoutP + n0 + co) * 16) : OOB;
     }
-    const unsigned wso = (unsigned)(q * 36 * CoutP * 16);
-    float4* dst = smem + b * BUF4 + i * 64;
-    const int idx = i * 64 + lane;
-    if (i * 64 + 64 <= NX4) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], xso, 0, 0);
-    } else if (i * 64 >= NX4) {
-      if (idx < BUF4) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], wso, 0, 0);
+  }
+  const bool low4 = wv < 4;
+  auto piece = [&](int q, int b, auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (q >= nq) return;
+    if ((j == 2 || j == 7) && !low4) return;
+    float4* base = smem + b * BUF4;
+    if (j < 3) {
+      unsigned xso = (unsigned)(8 * q * 4);
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c8 = 8 * q;
+        const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+      }
+      const int i = j < 2 ? wv + 8 * j : 16 + wv;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 64), 16, vo[j], xso, 0, 0);
     } else {
-      if (idx < NX4) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], xso, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, vo[j], wso, 0, 0);
+      const unsigned wso = (unsigned)(q * 36 * CoutP * 16);
+      const int i = j < 7 ? wv + 8 * (j - 3) : 32 + wv;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + NXP + i * 64), 16, vo[j], wso, 0, 0);
     }
   };
-  static_assert(NPW == 7, "piece schedule below assumes 7 DMA instructions per wave and chunk");
+  static_assert(NXI == 20 && NWI == 36, "piece schedule assumes 20 halo + 36 weight DMA instructions");
 
   // ---- MFMA role
   const int wg = wv & 3, nh = wv >> 2;             // row group, output-channel half
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const int tcol = ((l32 >> 2) & 1) + 2 * (l32 & 1);
   const int trow = 8 * (l32 >> 3) + 2 * wg + ((l32 >> 1) & 1);
   const int abase = (trow * IW + 4 * tcol) * 2 + hl;
-  const int wbase = NX4 + hl * BN + 32 * nh + l32;
+  const int wbase = NXP + hl * BN + 32 * nh + l32;
   f32x4 dn[6], V[2][6], Bv[2][6];
   auto ld_row = [&](int b, int r, int par) {
     const f32x4* xb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + abase + r * IW * 2;
@@ -807,42 +809,53 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
     V[par][4] = t5 - 2.f * t6;
     V[par][5] = 4.f * dn[1] - 5.f * dn[3] + dn[5];
   };
-  // 24 MFMAs of one kernel row; DMA pieces [j0, j0 + nj) of chunk dq into buffer db are issued between the k-step groups
-  auto mfma_row = [&](int par, int dq, int db, int j0, int nj) {
+  // 24 MFMAs of one kernel row; DMA pieces J0 .. J0 + NJ - 1 of chunk dq into buffer db are issued between the k-step groups
+  auto mfma_row = [&](int par, int dq, int db, auto j0c, auto njc) {
+    constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
       for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[par][p][e], Bv[par][p][e], acc[p], 0, 0, 0);
-      if (e < nj) { __builtin_amdgcn_sched_barrier(0); piece(dq, db, j0 + e); __builtin_amdgcn_sched_barrier(0); }
+      if (e < NJ) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (e == 0) piece(dq, db, std::integral_constant<int, J0>{});
+        if (e == 1) piece(dq, db, std::integral_constant<int, (NJ > 1 ? J0 + 1 : J0)>{});
+        if (e == 2) piece(dq, db, std::integral_constant<int, (NJ > 2 ? J0 + 2 : J0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
+  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using I5 = std::integral_constant<int, 5>;
   // chunk q sits in buffer b.  Chunk q+1 streams into b^1: its pieces 0-1 were issued behind the previous chunk's last
-  // row, 2-6 go behind rows 0 and 1 here; after the barrier b is free and chunk q+2's pieces 0-1 go behind row 2.
+  // row, 2-7 go behind rows 0 and 1 here; after the barrier b is free and chunk q+2's pieces 0-1 go behind row 2.
   auto chunk = [&](int q, auto P0c) {
     constexpr int P0 = decltype(P0c)::value;
     const int b = q & 1;
     const bool more = q + 1 < nq;
     ld_row(b, 1, P0 ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0, q + 1, b ^ 1, 2, 2);
+    mfma_row(P0, q + 1, b ^ 1, I2{}, I3{});
     __builtin_amdgcn_sched_barrier(0);
     transform(P0 ^ 1);
     ld_row(b, 2, P0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0 ^ 1, q + 1, b ^ 1, 4, 3);
+    mfma_row(P0 ^ 1, q + 1, b ^ 1, I5{}, I3{});
     __builtin_amdgcn_sched_barrier(0);
     transform(P0);
     __syncthreads();                             // buffer b consumed (row 2 in registers); chunk q+1 landed in b^1
     if (more) ld_row(b ^ 1, 0, P0 ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0, q + 2, b, 0, 2);                // tap row 2
+    mfma_row(P0, q + 2, b, I0{}, I2{});          // tap row 2
     __builtin_amdgcn_sched_barrier(0);
     if (more) transform(P0 ^ 1);
   };
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) piece(0, 0, j);
-  piece(1, 1, 0);
-  piece(1, 1, 1);
+  piece(0, 0, std::integral_constant<int, 0>{}); piece(0, 0, std::integral_constant<int, 1>{});
+  piece(0, 0, std::integral_constant<int, 2>{}); piece(0, 0, std::integral_constant<int, 3>{});
+  piece(0, 0, std::integral_constant<int, 4>{}); piece(0, 0, std::integral_constant<int, 5>{});
+  piece(0, 0, std::integral_constant<int, 6>{}); piece(0, 0, std::integral_constant<int, 7>{});
+  piece(1, 1, std::integral_constant<int, 0>{});
+  piece(1, 1, std::integral_constant<int, 1>{});
   __syncthreads();
   ld_row(0, 0, 0);
   transform(0);
