@@ -716,6 +716,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const int oh0 = ty * TH, ow0 = tx * SRK_TW, n0 = blockIdx.y * BN;
   const int CoutP = (a.Cout + 31) & ~31;
   const int nq = (a.Cin + 7) >> 3;
+  SRK_STAMP_AT(0);
 
   // ---- DMA plan.  Per chunk 20 halo + 36 weight instructions (1 KB each).  Piece j of a wave has a COMPILE-TIME kind so
   // that issuing it is an m0 update + one buffer_load...lds: j = 0, 1 -> halo instruction wv + 8j; j = 2 -> halo 16 + wv
@@ -856,7 +857,9 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   piece(0, 0, std::integral_constant<int, 6>{}); piece(0, 0, std::integral_constant<int, 7>{});
   piece(1, 1, std::integral_constant<int, 0>{});
   piece(1, 1, std::integral_constant<int, 1>{});
+  SRK_STAMP_AT(1);
   __syncthreads();
+  SRK_STAMP_AT(2);
   ld_row(0, 0, 0);
   transform(0);
   int q = 0;
@@ -865,6 +868,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
     chunk(q + 1, std::integral_constant<int, 1>{});
   }
   if (q < nq) chunk(q, std::integral_constant<int, 0>{});
+  SRK_STAMP_AT(3);
   // output transform: source register 4q+s -> epilogue tile q, registers 4s .. 4s+3 (columns 4*tcol .. +3)
   f32x16 out[4][1];
 #pragma unroll
@@ -880,6 +884,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       out[tq][0][4 * sx + 3] = (d12 + 8.f * d34) + m5;
     }
   conv_epilogue<32, 4>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
+  SRK_STAMP_AT(4);
 }
 
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>

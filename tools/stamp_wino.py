@@ -8,18 +8,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("super-resolution_amd")._lib
 lib = L.lib()
 N, H, W, F = int(os.environ.get("N", 16)), 64, 64, 64
+FMT = int(os.environ.get("FMT", 3))          # 3: F(2,3) kernel, 5: F(4,3) kernel
 for ci in (64, 320):
     buf = torch.randn(N, H, W, 320, device="cuda"); out = torch.empty(N, H, W, F, device="cuda")
     w = torch.randn(F, ci, 3, 3, device="cuda") * 0.02
-    wp = torch.empty(L.packed_floats(ci, F, 3), device="cuda")
-    t = L.PackTable(buf.device, 3); t.add(w, wp, M=F, k_off=0, k_len=ci, K_total=ci); t.run()
+    wp = torch.empty(L.packed_floats(ci, F, FMT), device="cuda")
+    t = L.PackTable(buf.device, FMT); t.add(w, wp, M=F, k_off=0, k_len=ci, K_total=ci); t.run()
     b = torch.zeros(F, device="cuda")
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
     lib.srk_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     for _ in range(3):
-        L.conv3x3(L.View(buf, 0, ci), wp, b, L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, slope=0.01, wp_format=3)
+        L.conv3x3(L.View(buf, 0, ci), wp, b, L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, slope=0.01, wp_format=FMT)
     torch.cuda.synchronize()
-    s = stamps.cpu().view(-1, 16)[:N * 16].double() * 0.01   # us (s_memrealtime, 100 MHz)
+    nwg = N * 16 if FMT == 3 else N * 8
+    s = stamps.cpu().view(-1, 16)[:nwg].double() * 0.01   # us (s_memrealtime, 100 MHz)
     t0 = s[:, 0].min()
     names = ["wave 0 starts", "before 1st barrier", "chunk 0 in LDS", "main loop done", "epilogue done"]
     print(f"Cin={ci}: workgroups={s.shape[0]}")
