@@ -110,6 +110,41 @@ def test_no_cpu_fallback(srk):
         D(torch.rand(1, 1, 16, 16))
     with pytest.raises(RuntimeError, match="GPU"):
         srk.SumPool2d(2)(torch.rand(1, 1, 4, 4))
+    C = srk.Conditional_Discriminator((1, 16, 16), [8, 16], num_upsample=1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        C(torch.rand(1, 1, 16, 16), torch.rand(1, 1, 8, 8))
+    # optional loss heads and the jet decode: HIP kernels only, no torch fallback
+    x = torch.rand(2, 1, 8, 8)
+    for fn in (lambda: srk.losses.soft_count(x), lambda: srk.losses.mask_l1(x, x), lambda: srk.losses.get_hitogram(x, 2),
+               lambda: srk.losses.softgreater(x, 0.1), lambda: srk.losses.nnz_mask(x),
+               lambda: srk.losses.DiffableHistogram([0.0, 0.5, 1.0]).forward_positive(x),
+               lambda: srk.datasets.extract_batch(torch.zeros(2, 9), 4, 4)):
+        with pytest.raises(RuntimeError):
+            fn()
+
+
+def test_conditional_discriminator_host_contract(srk):
+    """ctor signature, output_shape and state_dict keys of models.py:189-223 (checked against the reference's key list)."""
+    D = srk.Conditional_Discriminator((1, 32, 32), [8, 16, 16, 32], num_upsample=2)
+    assert tuple(D.output_shape) == (1, 2, 2)
+    keys = open(os.path.join(ROOT, "tests", "golden", "G13_state_keys.txt")).read().split()
+    assert list(D.state_dict().keys()) == keys
+    assert [tuple(v.shape) for k, v in D.state_dict().items() if k.startswith("endmodel.0.")] == [(16, 32, 3, 3), (16,)]
+
+
+def test_dataset_host_logic(srk):
+    """array-backed jet datasets: __len__/__getitem__ hand out raw rows; cutters match datasets.py:170-201 on CPU tensors."""
+    import numpy as np
+    rows = np.arange(3 * 9, dtype=np.float32).reshape(3, 9)
+    ds = srk.datasets.SparseJetDataset(rows, etaBins=4, phiBins=4, factor=2, amount=2)
+    assert len(ds) == 2 and torch.equal(ds[1]["rows"], torch.from_numpy(rows[1]))
+    x = torch.tensor([[[0.1, 2.0], [3.0, 0.5]]])
+    assert torch.equal(srk.datasets.Cutter(thres=1.0)(x), torch.tensor([[[0.0, 2.0], [3.0, 0.0]]]))
+    assert torch.equal(srk.datasets.Cutter(amount=1)(x), torch.tensor([[[0.0, 0.0], [3.0, 0.0]]]))
+    with pytest.raises(NotImplementedError):
+        srk.datasets.Cutter(1.0, 2)
+    with pytest.raises(NotImplementedError):
+        srk.datasets.get_dataset("h5", "x.h5", 8, 8)
 
 
 def test_product_never_imports_oracle():
