@@ -39,6 +39,10 @@ DEFAULTS = dict(
 )
 UNSUPPORTED_POSITIVE = ("lambda_wasser", "drop_rate", "second_discr_reset_interval")
 # the reference's loss_dict keys, in its order (esrgan.py:355-356)
+# flags the reference declares with type=float although their default.json value is an integer literal (esrgan.py:58-120)
+FLOAT_FLAGS = {"lr", "lr_g", "lr_d", "l2decay", "b1", "b2", "scaling_power", "pixel_multiplier", "lambda_pix", "lambda_hr", "lambda_adv",
+               "lambda_lr", "lambda_hist", "lambda_wasser", "lambda_nnz", "lambda_mask", "lambda_pow", "lambda_hit", "d_threshold",
+               "drop_rate", "res_scale", "lambda_reg", "wasserstein", "sigma", "hit_threshold"}
 LOSS_KEYS = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
              'pixel_loss_pow', 'lr_loss', 'lr_loss_pow', 'hist_loss', 'hist_loss_pow', 'nnz_loss', 'nnz_loss_pow', 'mask_loss',
              'mask_loss_pow', 'wasser_loss', 'wasser_loss_pow', 'hit_loss', 'hit_loss_pow', 'wasser_dist', 'wasser_dist_pow']
@@ -60,7 +64,7 @@ def get_parser(argv=None):
         elif v is None:
             ap.add_argument("--" + k, default=None, type=(float if k == "E_thres" else str))
         else:
-            ap.add_argument("--" + k, type=type(v), default=v)
+            ap.add_argument("--" + k, type=(float if k in FLOAT_FLAGS else type(v)), default=v)
     ap.add_argument("--default", type=str, default=None, help="json file with option overrides")
     opt = ap.parse_args(argv)
     if opt.default:
