@@ -190,19 +190,43 @@ def conv_pre(x, w, b, stride=1, in_slope=1.0, wp=None, wpt=None):
     return ConvPre.apply(x, w, b, stride, in_slope, wp, wpt)
 
 
+class _ToNHWC(torch.autograd.Function):
+    """NCHW -> NHWC copy whose gradient is again a CONTIGUOUS tensor (plain permute().contiguous() hands autograd a
+    permuted view back, and the reference's ``gradients.view(batch_size, -1)`` of the gradient penalty, esrgan.py:604,
+    needs a contiguous input gradient like nn.Conv2d's).  The pair is closed under differentiation (double backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ToNCHW.apply(g)
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ToNHWC.apply(g)
+
+
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """NCHW -> NHWC (free view when C == 1: the two layouts coincide)."""
     n, c, h, w = x.shape
     if c == 1:
         return x.reshape(n, h, w, 1)
-    return x.permute(0, 2, 3, 1).contiguous()
+    return _ToNHWC.apply(x)
 
 
 def to_nchw(x: torch.Tensor) -> torch.Tensor:
     n, h, w, c = x.shape
     if c == 1:
         return x.reshape(n, 1, h, w)
-    return x.permute(0, 3, 1, 2).contiguous()
+    return _ToNCHW.apply(x)
 
 
 class _SumPool(torch.autograd.Function):

@@ -193,6 +193,33 @@ def test_conditional_discriminator_golden(srk, golden_dir):
     assert c.grad is not None and torch.isfinite(c.grad).all() and c.grad.abs().max() > 0
 
 
+def test_three_channel_discriminator_gradient_penalty(srk):
+    """C = 3 (real NCHW <-> NHWC copies at the boundary): the input gradient is contiguous like nn.Conv2d's, so the reference's
+    ``gradients.view(batch_size, -1)`` (esrgan.py:604) works, and the penalty's double backward matches the oracle."""
+    ch = [8, 16]
+    D = srk.Markovian_Discriminator((3, 24, 20), ch).cuda()
+    sd = O.closed_form_fill({k: v.cpu() for k, v in D.state_dict().items()}, gain=2.0)
+    D.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    gt, gen = torch.rand(2, 3, 24, 20, generator=g), torch.rand(2, 3, 24, 20, generator=g)
+    eps = torch.rand(2, 1, 1, 1, generator=g)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lo, gpo = O.d_phase_loss(sdo, gt, gen, eps, 0.01, d_channels=ch)
+    lo.backward()
+    interp = (eps.cuda() * gt.cuda() + (1 - eps.cuda()) * gen.cuda()).requires_grad_(True)
+    pi = D(interp, None)
+    grads = torch.autograd.grad(outputs=pi, inputs=interp, grad_outputs=torch.ones_like(pi), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    assert grads.is_contiguous()
+    gp = ((grads.view(2, -1).norm(2, dim=1) - 1) ** 2).mean() * 0.01 / 2
+    assert abs(gp.item() - gpo.item()) < 2e-3 * abs(gpo.item())
+    crit = torch.nn.BCEWithLogitsLoss()
+    pr, pf = D(gt.cuda(), None), D(gen.cuda(), None)
+    loss = (crit(1e-7 + pr - pf.mean(0, keepdim=True), torch.ones_like(pr)) + crit(1e-7 + pf - pr.mean(0, keepdim=True), torch.zeros_like(pr))) / 2 + gp
+    loss.backward()
+    for k, p in D.named_parameters():
+        assert rel(p.grad.cpu(), sdo[k].grad) < GRAD_TOL, k
+
+
 def test_discriminator_ragged_shapes(srk):
     for shp in [(1, 80, 80), (1, 75, 75), (3, 40, 24)]:
         D = srk.Markovian_Discriminator(shp, [16, 32, 32, 64]).cuda()
