@@ -98,8 +98,11 @@ def sum_pool(x: Tensor, k: int) -> Tensor:
 
 
 # --------------------------------------------------------------------------- generator
+DROP_MASKS: Optional[dict] = None    # {dense-block prefix: [N, F, 1, 1] mask already divided by (1 - p)} -> Dropout2d of models.py:38-39
+
+
 def dense_residual_block(sd, prefix: str, x: Tensor) -> Tensor:
-    """models.py:34-41 (drop_rate=0)."""
+    """models.py:34-41; with DROP_MASKS set, the channel dropout of ``drop_rate > 0`` is applied with the given masks."""
     inputs = x
     out = x
     for k in range(1, 6):
@@ -107,6 +110,8 @@ def dense_residual_block(sd, prefix: str, x: Tensor) -> Tensor:
         if k < 5:
             out = lrelu(out, G_SLOPE)
         inputs = torch.cat([inputs, out], 1)
+    if DROP_MASKS is not None and prefix in DROP_MASKS:
+        out = out * DROP_MASKS[prefix]
     return out * INNER_RES_SCALE + x
 
 

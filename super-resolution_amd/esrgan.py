@@ -37,7 +37,7 @@ DEFAULTS = dict(
     fully_transposed_conv=False, num_final_res_blocks=0, synthetic_batches=100, hit_threshold=0.5, sigma=500, bins=10,
     batchwise_hist=False,
 )
-UNSUPPORTED_POSITIVE = ("lambda_wasser", "drop_rate", "second_discr_reset_interval")
+UNSUPPORTED_POSITIVE = ("lambda_wasser", "second_discr_reset_interval")
 # the reference's loss_dict keys, in its order (esrgan.py:355-356)
 # flags the reference declares with type=float although their default.json value is an integer literal (esrgan.py:58-120)
 FLOAT_FLAGS = {"lr", "lr_g", "lr_d", "l2decay", "b1", "b2", "scaling_power", "pixel_multiplier", "lambda_pix", "lambda_hr", "lambda_adv",
@@ -172,7 +172,7 @@ def train(opt, **kwargs):
                         scaling_power=opt.scaling_power, multiplier=opt.pixel_multiplier, hr_shape=(opt.hr_height, opt.hr_width),
                         num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init, lambda_nnz=opt.lambda_nnz,
                         lambda_mask=opt.lambda_mask, lambda_hit=opt.lambda_hit, lambda_hist=opt.lambda_hist,
-                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional)
+                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional, drop_rate=opt.drop_rate)
     if opt.E_thres:
         st.generator.thres = opt.E_thres
     load_chk = bool(opt.load_checkpoint)

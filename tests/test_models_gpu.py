@@ -103,6 +103,49 @@ def test_generator_three_channel_photographic_config(srk):
     gen._engine.precision = "f32"
 
 
+def test_generator_with_dropout_branch(srk):
+    """drop_rate > 0 (models.py:29-31,38-39): Dropout2d on each dense block's last conv, run module-wise on the HIP convolutions.
+    Eval mode equals the no-dropout generator; in train mode the channel masks drawn by torch are captured with forward hooks
+    and replayed in the oracle (forward and all weight gradients)."""
+    gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1, drop_rate=0.3).cuda()
+    sd = _load_closed_form(gen)
+    assert list(gen.state_dict().keys()) == list(srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1).state_dict().keys())
+    x = torch.rand(3, 1, 12, 10) * 2
+    gen.eval()
+    with torch.no_grad():
+        ye = gen(x.cuda()).cpu()
+    yo_eval, _ = O.generator_forward(sd, x, 1, 1, 0.2, training=False)
+    assert rel(ye, yo_eval) < OUT_TOL
+    gen.train()
+    masks, hooks = {}, []
+    for name, m in gen.named_modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            def hook(mod, inp, out, name=name):
+                i = inp[0].detach()
+                ratio = torch.where(i != 0, out.detach() / torch.where(i != 0, i, torch.ones_like(i)), torch.zeros_like(i))
+                masks[name.rsplit(".", 1)[0]] = ratio.amax(dim=(2, 3), keepdim=True).cpu()     # [N, F, 1, 1]: 0 or 1/(1-p)
+            hooks.append(m.register_forward_hook(hook))
+    y = gen(x.cuda())
+    tgt = torch.rand(y.shape, generator=torch.Generator().manual_seed(1))
+    (y - tgt.cuda()).abs().mean().backward()
+    for h in hooks:
+        h.remove()
+    assert len(masks) == 3
+    for m in masks.values():
+        assert all(v == 0.0 or abs(v - 1 / 0.7) < 1e-5 for v in torch.unique(m).tolist())
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    O.DROP_MASKS = masks
+    try:
+        yo, _ = O.generator_forward(sdo, x, 1, 1, 0.2, training=True)
+    finally:
+        O.DROP_MASKS = None
+    assert rel(y.detach().cpu(), yo.detach()) < OUT_TOL
+    (yo - tgt).abs().mean().backward()
+    for k, p in gen.named_parameters():
+        if p.grad is not None:
+            assert rel(p.grad.cpu(), sdo[k].grad) < GRAD_TOL, k
+
+
 def test_generator_power_multiplier(srk):
     gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1, num_upsample=1, power=0.5, multiplier=2.0).cuda()
     sd = _load_closed_form(gen)
