@@ -96,9 +96,13 @@ def test_unsupported_branches_raise(srk):
     with pytest.raises(NotImplementedError):
         srk.GeneratorRRDB(use_transposed_conv=True)
     with pytest.raises(NotImplementedError):
-        srk.GeneratorRRDB(drop_rate=0.1)
-    with pytest.raises(NotImplementedError):
         srk.Conv3x3(3, 3, 5, 1, 2)
+    # drop_rate > 0 is supported (module-wise branch): same state_dict keys, Dropout2d modules hold no parameters
+    g = srk.GeneratorRRDB(1, 16, 1, drop_rate=0.1)
+    assert list(g.state_dict().keys()) == list(srk.GeneratorRRDB(1, 16, 1).state_dict().keys())
+    assert sum(isinstance(m, torch.nn.Dropout2d) for m in g.modules()) == 3
+    with pytest.raises(RuntimeError, match="GPU"):
+        g(torch.rand(1, 1, 8, 8))
 
 
 def test_no_cpu_fallback(srk):
