@@ -244,6 +244,20 @@ def discriminator_forward(sd, img: Tensor, channels=(16, 32, 32, 64)) -> Tensor:
     return conv3x3(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], 1)
 
 
+def standard_discriminator_forward(sd, img: Tensor, channels=(16, 32, 32, 64)) -> Tensor:
+    """Standard_Discriminator.forward (models.py:177-186): the patch trunk WITHOUT its final 1-channel conv (``model[:-1]``
+    keeps the trailing LeakyReLU), flattened into Linear(., 1024) -> ReLU -> Linear(1024, 1)."""
+    x = img
+    idx = 0
+    for _ in channels:
+        x = lrelu(conv3x3(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], 1), D_SLOPE)
+        x = lrelu(conv3x3(x, sd[f"model.{idx+2}.weight"], sd[f"model.{idx+2}.bias"], 2), D_SLOPE)
+        idx += 4
+    x = x.reshape(img.shape[0], -1)
+    x = F.relu(F.linear(x, sd["fc.0.weight"], sd["fc.0.bias"]))
+    return F.linear(x, sd["fc.2.weight"], sd["fc.2.bias"])
+
+
 def conditional_discriminator_forward(sd, img: Tensor, cond: Tensor, channels=(32, 64, 128, 256), num_upsample=3) -> Tensor:
     """Conditional_Discriminator.forward (models.py:189-223): the HR image goes through ``num_upsample`` stride-(1,2)
     blocks (model_hr), the LR condition through as many stride-(1,1) blocks (model_c); their outputs are concatenated

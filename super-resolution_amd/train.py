@@ -45,7 +45,7 @@ class Stepper:
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
                  exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
-                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0):
+                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0, discriminator="patch"):
         self.workload = workload
         self.drop_rate = drop_rate
         self.conditional = conditional
@@ -80,6 +80,8 @@ class Stepper:
                     if conditional:       # esrgan.py:213-219
                         D = models.Conditional_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels),
                                                              num_upsample=int(math.log2(factor))).to(device)
+                    elif discriminator == "standard":     # esrgan.py:205-207
+                        D = models.Standard_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     else:
                         D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     self.discriminators[k] = D

@@ -263,6 +263,29 @@ def test_three_channel_discriminator_gradient_penalty(srk):
         assert rel(p.grad.cpu(), sdo[k].grad) < GRAD_TOL, k
 
 
+def test_standard_discriminator_golden(srk, golden_dir):
+    """Standard_Discriminator (models.py:177-186: patch trunk without its last conv + Linear-ReLU-Linear head) forward,
+    relativistic loss and gradients against the reference-generated G15."""
+    d = np.load(os.path.join(golden_dir, "G15_standard_discriminator.npz"))
+    S = srk.Standard_Discriminator((1, 32, 32), [8, 16]).cuda()
+    assert list(S.state_dict().keys()) == open(os.path.join(golden_dir, "G15_state_keys.txt")).read().split()
+    _load_closed_form(S, gain=2.0)
+    assert tuple(S.output_shape) == tuple(int(v) for v in d["out_shape"])
+    gt, gen = torch.from_numpy(d["gt"]).cuda(), torch.from_numpy(d["gen"]).cuda()
+    pr, pf = S(gt, None), S(gen, None)
+    assert rel(pr.detach().cpu(), torch.from_numpy(d["pred_real"])) < OUT_TOL and rel(pf.detach().cpu(), torch.from_numpy(d["pred_fake"])) < OUT_TOL
+    crit = torch.nn.BCEWithLogitsLoss()
+    loss = (crit(1e-7 + pr - pf.mean(0, keepdim=True), torch.ones_like(pr)) + crit(1e-7 + pf - pr.mean(0, keepdim=True), torch.zeros_like(pr))) / 2
+    assert abs(loss.item() - float(d["loss"])) < 1e-4 * max(1.0, abs(float(d["loss"])))
+    loss.backward()
+    for k, p in S.named_parameters():
+        g = p.grad.cpu()
+        if k == "fc.0.weight":
+            assert abs(g.double().abs().sum().item() - float(d["gradsum." + k])) < 2e-3 * float(d["gradsum." + k])
+            g = g[:16]
+        assert rel(g, torch.from_numpy(d["grad." + k])) < GRAD_TOL, k
+
+
 def test_discriminator_ragged_shapes(srk):
     for shp in [(1, 80, 80), (1, 75, 75), (3, 40, 24)]:
         D = srk.Markovian_Discriminator(shp, [16, 32, 32, 64]).cuda()

@@ -63,3 +63,29 @@ np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else n
 with open(os.path.join(ROOT, "tests", "golden", "G13_state_keys.txt"), "w") as f:
     f.write("\n".join(D.state_dict().keys()) + "\n")
 print("wrote", path, os.path.getsize(path), "output_shape", D.output_shape, "keys", len(D.state_dict()))
+
+# ---- G15: Standard_Discriminator (models.py:177-186): forward, relativistic loss (mean over the batch of a [B, 1] output), grads
+S = ref.Standard_Discriminator((1, HR, HR), [8, 16])
+ssd = O.closed_form_fill(S.state_dict(), gain=2.0)
+S.load_state_dict(ssd)
+pr, pf = S(gt, lr), S(gen, lr)
+v1, f1 = torch.ones(3, *S.output_shape), torch.zeros(3, *S.output_shape)
+lS = (crit(1e-7 + pr - pf.mean(0, keepdim=True), v1) + crit(1e-7 + pf - pr.mean(0, keepdim=True), f1)) / 2
+S.zero_grad(); lS.backward()
+so = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+pro, pfo = O.standard_discriminator_forward(so, gt, [8, 16]), O.standard_discriminator_forward(so, gen, [8, 16])
+lo2 = (O.bce_logits(1e-7 + pro - pfo.mean(0, keepdim=True), v1) + O.bce_logits(1e-7 + pfo - pro.mean(0, keepdim=True), f1)) / 2
+lo2.backward()
+close(pro, pr, what="std fwd"); close(lo2, lS, what="std loss")
+arrs2 = dict(gt=gt, gen=gen, pred_real=pr.detach(), pred_fake=pf.detach(), loss=lS.detach(), out_shape=np.array(S.output_shape, dtype=np.int64))
+for k, p in S.named_parameters():
+    close(so[k].grad, p.grad, tol=2e-6, what="std grad " + k)
+    # fc.0.weight's gradient is 1024 x 1024: keep a 16-row slice and its total instead of 4 MB
+    arrs2["grad." + k] = p.grad[:16].clone() if k == "fc.0.weight" else p.grad
+    if k == "fc.0.weight":
+        arrs2["gradsum." + k] = p.grad.double().abs().sum()
+path2 = os.path.join(ROOT, "tests", "golden", "G15_standard_discriminator.npz")
+np.savez_compressed(path2, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs2.items()})
+with open(os.path.join(ROOT, "tests", "golden", "G15_state_keys.txt"), "w") as f:
+    f.write("\n".join(S.state_dict().keys()) + "\n")
+print("wrote", path2, os.path.getsize(path2), "output_shape", S.output_shape)
