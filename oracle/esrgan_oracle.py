@@ -388,7 +388,8 @@ def hist_binedges(nnz, bins: int, power: float = 1.0):
 def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Sequence[dict],
                  factor: int, scaling_power: float = 1.0, lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1,
-                 d_channels=(16, 32, 32, 64), heads: Optional[dict] = None, cond_num_upsample: Optional[int] = None):
+                 d_channels=(16, 32, 32, 64), heads: Optional[dict] = None, cond_num_upsample: Optional[int] = None,
+                 relativistic: bool = True):
     """esrgan.py:468-552 (relativistic; hr+lr+adv terms, plus the optional heads of esrgan.py:522-547 when ``heads`` =
     dict(lambda_nnz, lambda_mask, lambda_hit, hit_threshold, sigma, lambda_hist, binedges=[edges_def, edges_pow]) is given).
     ``generated`` = [G(lr), G.srs].  Returns (loss_G, dict of parts)."""
@@ -411,8 +412,11 @@ def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Seq
             pred_fake = discriminator_forward(d_sds[k], generated[k], d_channels)
         valid = torch.ones_like(pred_real)
         fake = torch.zeros_like(pred_real)
-        loss_gan = 0.5 * (bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), valid) +
-                          bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), fake))
+        if relativistic:
+            loss_gan = 0.5 * (bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), valid) +
+                              bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), fake))
+        else:                                               # esrgan.py:509-510
+            loss_gan = bce_logits(EPS + pred_fake, valid)
         tot = lambda_hr * loss_pixel + lambda_adv * loss_gan + lambda_lr * loss_lr
         parts[k] = dict(pixel=loss_pixel, lr=loss_lr, adv=loss_gan)
         h = heads or {}
@@ -441,7 +445,8 @@ def g_phase_loss(generated: Sequence[Tensor], hr: Tensor, lr: Tensor, d_sds: Seq
 
 
 def d_phase_loss(d_sd: dict, gt: Tensor, gen_detached: Tensor, epsilon: Optional[Tensor],
-                 lambda_reg=0.01, d_channels=(16, 32, 32, 64), cond: Optional[Tensor] = None, num_upsample: int = 0):
+                 lambda_reg=0.01, d_channels=(16, 32, 32, 64), cond: Optional[Tensor] = None, num_upsample: int = 0,
+                 relativistic: bool = True):
     """esrgan.py:569-606 for one discriminator (relativistic + gradient penalty).
     ``epsilon``: (B,1,1,1) interpolation factors (esrgan.py:598) or None to skip GP.
     ``cond`` (the LR ground truth, esrgan.py:569-570,601) selects the Conditional_Discriminator."""
@@ -454,8 +459,12 @@ def d_phase_loss(d_sd: dict, gt: Tensor, gen_detached: Tensor, epsilon: Optional
     pred_fake = discriminator_forward(d_sd, gen_detached, d_channels)
     valid = torch.ones_like(pred_real)
     fake = torch.zeros_like(pred_real)
-    loss_real = bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), valid)
-    loss_fake = bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), fake)
+    if relativistic:
+        loss_real = bce_logits(EPS + pred_real - pred_fake.mean(0, keepdim=True), valid)
+        loss_fake = bce_logits(EPS + pred_fake - pred_real.mean(0, keepdim=True), fake)
+    else:                                                   # esrgan.py:584-586
+        loss_real = bce_logits(EPS + pred_real, valid)
+        loss_fake = bce_logits(EPS + pred_fake, fake)
     loss_D = (loss_real + loss_fake) / 2
     gp = None
     if lambda_reg > 0 and epsilon is not None:

@@ -107,8 +107,6 @@ def _check_supported(opt):
             raise NotImplementedError(f"option {k} > 0 is outside the hot path implemented by this build (SURVEY.md 2.1)")
     if opt.discriminator not in ("patch", "standard") or opt.wasserstein > 0:
         raise NotImplementedError("only the patch (Markovian), standard and conditional discriminators with the relativistic loss are implemented")
-    if not opt.relativistic:
-        raise NotImplementedError("non-relativistic adversarial loss is not implemented")
     if opt.use_transposed_conv or opt.fully_transposed_conv:
         raise NotImplementedError("transposed-conv upsampling branches are not implemented")
 
@@ -172,7 +170,7 @@ def train(opt, **kwargs):
                         scaling_power=opt.scaling_power, multiplier=opt.pixel_multiplier, hr_shape=(opt.hr_height, opt.hr_width),
                         num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init, lambda_nnz=opt.lambda_nnz,
                         lambda_mask=opt.lambda_mask, lambda_hit=opt.lambda_hit, lambda_hist=opt.lambda_hist,
-                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional, drop_rate=opt.drop_rate, discriminator=opt.discriminator)
+                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional, drop_rate=opt.drop_rate, discriminator=opt.discriminator, relativistic=opt.relativistic)
     if opt.E_thres:
         st.generator.thres = opt.E_thres
     load_chk = bool(opt.load_checkpoint)

@@ -45,9 +45,10 @@ class Stepper:
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
                  exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
-                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0, discriminator="patch"):
+                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0, discriminator="patch", relativistic=True):
         self.workload = workload
         self.drop_rate = drop_rate
+        self.relativistic = relativistic
         self.conditional = conditional
         # optional physics heads of the G phase (esrgan.py:522-547); the histogram head needs set_hist_binedges() first
         self.lambda_nnz, self.lambda_mask, self.lambda_hit, self.lambda_hist = lambda_nnz, lambda_mask, lambda_hit, lambda_hist
@@ -180,8 +181,11 @@ class Stepper:
                 q.requires_grad_(True)
             valid = torch.ones_like(pred_real)
             fake = torch.zeros_like(pred_real)
-            loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
-                             self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
+            if self.relativistic:      # esrgan.py:498-508
+                loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
+                                 self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
+            else:                      # esrgan.py:509-510
+                loss_GAN = self.criterion_GAN(EPS + pred_fake, valid)
             tot = self.lambda_hr * loss_pixel + self.lambda_adv * loss_GAN + self.lambda_lr * loss_lr_pixel
             parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach())
             # optional physics heads: one fused HIP pass each (csrc/srk_loss.hip) instead of 3-6 HR-sized ATen ops.
@@ -220,8 +224,12 @@ class Stepper:
         pred_fake = D(gen_detached, cond)
         valid = torch.ones_like(pred_real)
         fake = torch.zeros_like(pred_real)
-        loss_real = self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), valid)
-        loss_fake = self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), fake)
+        if self.relativistic:          # esrgan.py:576-583
+            loss_real = self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), valid)
+            loss_fake = self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), fake)
+        else:                          # esrgan.py:584-586
+            loss_real = self.criterion_GAN(EPS + pred_real, valid)
+            loss_fake = self.criterion_GAN(EPS + pred_fake, fake)
         loss_D = (loss_real + loss_fake) / 2
         gp = None
         if self.lambda_reg > 0:

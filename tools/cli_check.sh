@@ -13,6 +13,7 @@ echo "== json default"; echo '{"lambda_adv": 0.02, "res_scale": 0.2, "update_d":
 echo "== scaling_power + E_thres + final res blocks"; python tools/train.py $COMMON --name sp --scaling_power 0.5 --E_thres 0.1 --num_final_res_blocks 1 --lambda_pow 0.5 2>&1 | tail -1 | cut -c1-200
 echo "== update_g 2, d_threshold high"; python tools/train.py $COMMON --name ug --update_g 2 --d_threshold 10 2>&1 | tail -1 | cut -c1-200
 echo "== standard discriminator"; python tools/train.py $COMMON --name std --discriminator standard --d_channels 8 16 2>&1 | tail -1 | cut -c1-200
+echo "== non-relativistic"; python tools/train.py $COMMON --name nr --relativistic false 2>&1 | tail -1 | cut -c1-200
 echo "== drop_rate"; python tools/train.py $COMMON --name dr --drop_rate 0.2 2>&1 | tail -1 | cut -c1-200
 echo "== 3 channels, factor 4"; python tools/train.py --residual_blocks 1 --factor 4 --hr_height 32 --hr_width 48 --channels 3 --batch_size 2 --n_batches 4 --warmup_batches 1 --report_freq 1 --synthetic_batches 3 --root $O --name c3 2>&1 | tail -1 | cut -c1-200
 echo "== sparse jets from a .npy row table"
