@@ -326,7 +326,17 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform, provably so (SGPR): DMA bases, branches
   const int hl = lane >> 5, l32 = lane & 31;
   const int wa = wv & 1, wb = (wv >> 1) & 1, ks = wv >> 2;
-  const int p = blockIdx.x, chunk = blockIdx.y;
+  // XCD-aware id -> (pixel split p, chunk): workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), and
+  // all chunks of one pixel split read the SAME x / dy tiles at about the same time.  With P a multiple of 8 the chunks of
+  // split p all land on XCD p % 8, so those tiles come from HBM once per XCD instead of once per chunk (measured on the
+  // dense-block batch: 1153 -> ~340 MB per launch, the algorithmic 336).  The first (P & ~7) splits are placed that way, the
+  // remaining P % 8 splits follow in plain order.
+  int p, chunk;
+  {
+    const int id = blockIdx.x, nc = B.n_chunks, pm = B.P & ~7;
+    if (id < pm * nc) { const int s_ = id >> 3; p = (id & 7) + 8 * (s_ / nc); chunk = s_ - (s_ / nc) * nc; }
+    else { const int r_ = id - pm * nc; p = pm + r_ / nc; chunk = r_ - (r_ / nc) * nc; }
+  }
   // everything about the problem is workgroup-uniform: keep it in SGPRs (the byte tables are read through a VGPR otherwise,
   // which would turn every buffer descriptor below into a waterfall loop)
   const int pi = __builtin_amdgcn_readfirstlane(B.c_prob[chunk]);
@@ -1035,7 +1045,7 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     if (!ks_env) ksp = 1;
   }
   if (S == 1 && VEC && B.wino)
-    hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), grid, dim3(WW_THREADS), 0, st, B, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(WW_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 4)
     hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 2)
