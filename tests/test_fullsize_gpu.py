@@ -130,3 +130,25 @@ def test_full_generator_forward_vs_oracle(full_generator):
             err = ((y - ref).abs().max() / ref.abs().max()).item()
             assert err < tol, (mode, err)
     gen._engine.precision = "f32"
+
+
+def test_generator_with_f43_kernels_on_ragged_width_vs_oracle(srk):
+    """A launch big enough for the engine to pick the Winograd F(4,3) kernels (>= 200 workgroups of 32 x 16) with a width that
+    is not a multiple of the tile (72 = 4.5 tiles): forward and all weight gradients of a one-RRDB generator vs the oracle."""
+    gen = srk.GeneratorRRDB(1, filters=64, num_res_blocks=1, num_upsample=1).cuda()
+    sd = O.default_init_generator(3, channels=1, filters=64, num_res_blocks=1, num_upsample=1)
+    gen.load_state_dict(sd)
+    N, H, W = 20, 64, 72
+    assert gen._engine._wino4_levels((N, H, W)) == (True, True)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(N, 1, H, W, generator=g) * (torch.rand(N, 1, H, W, generator=g) < 0.2) * 5
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, x, 1, 1, 0.2, training=True)
+    tgt = torch.rand(yo.shape, generator=g)
+    (yo - tgt).abs().mean().backward()
+    y = gen(x.cuda())
+    assert ((y.detach().cpu() - yo.detach()).abs().max() / yo.detach().abs().max()).item() < 2e-5
+    (y - tgt.cuda()).abs().mean().backward()
+    worst = max(((p.grad.cpu() - sdo[k].grad).abs().max() / sdo[k].grad.abs().max().clamp_min(1e-4)).item()
+                for k, p in gen.named_parameters() if p.grad is not None)
+    assert worst < 2e-3, worst
