@@ -158,9 +158,15 @@ class GeneratorEngine:
         return convs
 
     def params(self) -> List[torch.nn.Parameter]:
+        # called twice per iteration (forward + backward) on the host's critical path right after the D-gate sync: the module
+        # list is fixed after construction, and Parameters are read from the modules' dicts (nn.Module.__getattr__ is slow)
+        mods = getattr(self, "_conv_mods", None)
+        if mods is None:
+            mods = self._conv_mods = [m for _, m in self._conv_modules()]
         ps = []
-        for _, m in self._conv_modules():
-            ps += [m.weight, m.bias]
+        for m in mods:
+            pd = m._parameters
+            ps.append(pd["weight"]); ps.append(pd["bias"])
         return ps
 
     def _build_tables(self, device, geo):
