@@ -12,6 +12,12 @@
 // chunk).  The epilogue fuses bias, residual adds (x2), LeakyReLU, LeakyReLU-backward masking, the
 // channel-slice store of the concat-free dense block and PixelShuffle(2).
 //
+// Four kernels share that structure and one epilogue (srk_epilogue.h); srk_conv3x3() picks by srk_conv_args.wp_format and geometry:
+//   conv3x3_f32_kernel        direct, register-staged: stride 2, zero-upsample, small / unaligned channel counts
+//   conv3x3_f32_lw_kernel     direct, a fifth wave stages global->LDS (stride 1, 64-channel tiles)
+//   conv3x3_f32_wino_kernel   Winograd F(2,3) along W (wp_format 3): 2/3 of the MFMAs, 16x16 tiles, loader wave
+//   conv3x3_f32_wino4_kernel  Winograd F(4,3) along W (wp_format 5): 1/2 of the MFMAs, 32x16 tiles, DMA staging
+//
 // Mirrors: nn.Conv2d/LeakyReLU/cat/mul+add/PixelShuffle of /root/reference/models.py:19-21,36-41,53,
 // 63,67,86-90,97-99,126,142-145,168 (forward) and their autograd data-gradients.
 #include "srk_internal.h"

@@ -16,6 +16,10 @@
 // transposes through LDS so that the canonical OIHW rows are written coalesced, undoes the PixelShuffle
 // packing and applies scale / accumulate.
 //
+// Kernels: wgrad_f32_kernel (direct; KSP = 2/4 pixel-split variants for small channel counts), wgrad_f32_wino_kernel
+// (transposed Winograd F(2,3) on column pairs, DMA-staged, the generator's weight gradients), wgrad_c1_kernel (Cin == 1,
+// streaming), wgrad_bf16x3_kernel (opt-in split-bf16), and the deterministic reductions wgrad_prereduce / wgrad_reduce.
+//
 // Mirrors the autograd weight/bias gradient of nn.Conv2d at /root/reference/models.py:19,63,67,87,97,99,
 // 142,144,168.
 #include "srk_internal.h"
