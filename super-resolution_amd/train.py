@@ -255,6 +255,9 @@ class Stepper:
             if self.drop_rate > 0:
                 self._sync_grads(self.generator)
             self.optimizer_G.step()
+            # drop the 702 gradient views now, while the GPU is busy with the D phase: at the top of the next iteration this
+            # loop would sit on the host's critical path right after the discriminator gate's sync
+            self.optimizer_G.zero_grad(set_to_none=True)
         else:       # the D phase still needs the generator output (esrgan.py:457 skips only the G update)
             with torch.no_grad():
                 generated = [self.generator(imgs_lr), self.generator.srs]
