@@ -126,6 +126,30 @@ def test_heads_full_size_properties(LS):
     assert rel(hh.sum(), torch.tensor(float((gen > 0).sum().item()))) < 0.2      # nearly every positive entry falls in one of the 10 bins
 
 
+def test_soft_hist_many_bins_and_unaligned_sizes(LS):
+    """K = 40 bins (the 64-wide accumulator variant), element counts that are not multiples of 4 (scalar paths of the
+    elementwise / reduction kernels), values and gradients vs the oracle."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(3, 1, 7, 11, generator=g) * 6 - 1)
+    edges = np.linspace(0.0, 5.0, 41)
+    xo = x.clone().requires_grad_(True); xg = x.cuda().requires_grad_(True)
+    w = torch.rand(1, 40, generator=g)
+    ho = O.diffable_histogram(xo[xo > 0], edges, 7.0)
+    (ho * w).sum().backward()
+    hist = LS.DiffableHistogram(edges, sigma=7.0).to("cuda")
+    hg = hist.forward_positive(xg)
+    (hg * w.cuda()).sum().backward()
+    assert rel(hg, ho) < VT and rel(xg.grad, xo.grad) < GT * 5
+    assert rel(hist(xg.detach()), O.diffable_histogram(x, edges, 7.0)) < VT
+    with pytest.raises(RuntimeError):
+        LS.DiffableHistogram(np.linspace(0, 1, 70), sigma=1.0).to("cuda").forward_positive(xg)      # > 64 bins: unsupported
+    # elementwise functions on 231 (odd) elements
+    y = LS.softgreater(xg, 0.3, 9.0, 0.1)
+    assert rel(y, O.softgreater(x, 0.3, 9.0, 0.1)) < VT
+    assert rel(LS.soft_count(xg, 0.0, 4.0), O.softgreater(x, 0, 4.0).sum((1, 2, 3))) < VT
+    assert abs(LS.mask_l1(xg, xg.detach() * 0.5, 3.0).item() - (O.nnz_mask(x, 3.0) - O.nnz_mask(x * 0.5, 3.0)).abs().mean().item()) < 1e-6
+
+
 def test_heads_fail_loudly_on_cpu_and_bad_args(LS):
     with pytest.raises(RuntimeError):
         LS.soft_count(torch.zeros(2, 1, 4, 4))
