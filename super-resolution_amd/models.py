@@ -182,21 +182,15 @@ class Markovian_Discriminator(nn.Module):
 
     def __init__(self, input_shape, channels=[16, 32, 32, 64]):
         super().__init__()
-        self.channels = channels
-        self.input_shape = input_shape
-        in_channels, in_height, in_width = self.input_shape
-
-        def stride2(x):
-            return int(np.ceil(x / 2))
-        patch_h, patch_w = in_height, in_width
+        self.channels, self.input_shape = channels, input_shape
+        c_img, h, w = input_shape
+        widths = [c_img] + list(channels)
         layers = []
-        in_filters = in_channels
-        for out_filters in self.channels:
-            layers.extend(discriminator_block(in_filters, out_filters))
-            in_filters = out_filters
-            patch_h, patch_w = stride2(patch_h), stride2(patch_w)
-        layers.append(Conv3x3(in_filters, 1, kernel_size=3, stride=1, padding=1))
-        self.output_shape = (1, patch_h, patch_w)
+        for cin, cout in zip(widths[:-1], widths[1:]):      # one (stride 1, stride 2) block per entry: the patch grid halves (ceil)
+            layers += discriminator_block(cin, cout)
+            h, w = -(-h // 2), -(-w // 2)
+        layers.append(Conv3x3(widths[-1], 1, kernel_size=3, stride=1, padding=1))
+        self.output_shape = (1, h, w)
         self.model = nn.Sequential(*layers)
         self._packed = None
 
@@ -268,30 +262,24 @@ class Conditional_Discriminator(nn.Module):
 
     def __init__(self, input_shape, channels=[32, 64, 128, 256], num_upsample=3):
         super().__init__()
-        self.channels = channels
-        self.input_shape = input_shape
-        in_channels, in_height, in_width = self.input_shape
-
-        def stride2(x):
-            return int(np.ceil(x / 2))
-        patch_h, patch_w = in_height, in_width
-        hrlayers, clayers, endlayers = [], [], []
-        in_filters = in_channels
-        for i, out_filters in enumerate(self.channels):
+        self.channels, self.input_shape = channels, input_shape
+        c_img, h, w = input_shape
+        # block i < num_upsample: one stride-2 block on the image branch and one stride-1 block on the condition branch;
+        # block num_upsample takes the concatenation (2x channels); every block halves the patch grid (ceil)
+        branches = {"hr": [], "c": [], "end": []}
+        widths = [c_img] + list(channels)
+        for i, (cin, cout) in enumerate(zip(widths[:-1], widths[1:])):
             if i < num_upsample:
-                hrlayers.extend(discriminator_block(in_filters, out_filters))
-                clayers.extend(discriminator_block(in_filters, out_filters, stride=(1, 1)))
-            elif i == num_upsample:
-                endlayers.extend(discriminator_block(in_filters * 2, out_filters))
+                branches["hr"] += discriminator_block(cin, cout)
+                branches["c"] += discriminator_block(cin, cout, stride=(1, 1))
             else:
-                endlayers.extend(discriminator_block(in_filters, out_filters))
-            in_filters = out_filters
-            patch_h, patch_w = stride2(patch_h), stride2(patch_w)
-        endlayers.append(Conv3x3(out_filters, 1, kernel_size=3, stride=1, padding=1))
-        self.output_shape = (1, patch_h, patch_w)
-        self.model_hr = nn.Sequential(*hrlayers)
-        self.model_c = nn.Sequential(*clayers)
-        self.endmodel = nn.Sequential(*endlayers)
+                branches["end"] += discriminator_block(2 * cin if i == num_upsample else cin, cout)
+            h, w = -(-h // 2), -(-w // 2)
+        branches["end"].append(Conv3x3(widths[-1], 1, kernel_size=3, stride=1, padding=1))
+        self.output_shape = (1, h, w)
+        self.model_hr = nn.Sequential(*branches["hr"])
+        self.model_c = nn.Sequential(*branches["c"])
+        self.endmodel = nn.Sequential(*branches["end"])
         self._packed = None
 
     def forward(self, img, cond):
