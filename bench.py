@@ -144,6 +144,22 @@ def full_size_parity(sr, res_blocks, dev):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `torch.distributed.run` with N ranks on this node as a child
+    process (never an exec: this process stays a plain parent that has not initialised the GPU) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -151,8 +167,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: start the N ranks ourselves, BEFORE anything touches the GPU
+        # (importing torch does not), as children of this process; rank 0's JSON line passes through on stdout.
+        raise SystemExit(self_launch(args.gpus))
+    backend = os.environ.get("SRK_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks sharing one GPU (RCCL refuses that)
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sr = importlib.import_module("super-resolution_amd")
@@ -166,7 +187,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     batch = args.batch or (16 if args.workload == "g_only" else 32)
     torch.manual_seed(0)                                  # identical replicas on every rank
@@ -231,29 +255,34 @@ def main():
             dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"])
             name, st = dom
             ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
-            traffic = None
+            peak_tflops = F32_MFMA_PEAK_TFLOPS
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:   # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                     # same command (tools/traffic_from_pmc.py; FETCH_SIZE x2 on gfx950), not collectable in-process
                     traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command on an earlier box (PMC counters cannot be read in-process); not measured in this run")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            # `frac` is the fraction of the fp32 matrix pipe's peak that the kernel SUSTAINS: executed multiply-adds / time / peak.
+            # The Winograd kernels execute fewer multiply-adds than the convolution's algorithmic count -- F(2,3) along W:
+            # 4 instead of 6 per output pair (2/3); F(4,3): 6 instead of 12 per output quad (1/2) -- so the algorithmic-equivalent
+            # rate (what a direct kernel would need to match the time) is reported beside it and may exceed the peak.
+            fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach * fac, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                    "frac": round(ach * fac / peak_tflops, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
                     "avg_gflop_per_launch": round(st["flops"] / st["n"] / 1e9, 3),
-                    "probe": "events around every conv/wgrad launch of the first timed step",
-                    "conv_time_share_of_probed_step": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4)}
-            if "wino" in name:
-                # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2*N*OH*OW*Cout*Cin*9).  The Winograd kernels issue
-                # fewer multiply-adds -- F(2,3) along W: 4 instead of 6 per output pair (2/3), F(4,3): 6 instead of 12 per output
-                # quad (1/2) -- which is why `frac` may exceed 1: the matrix pipe itself runs at executed = factor * achieved.
-                fac, what = (0.5, "F(4,3)") if "wino4" in name else (2.0 / 3.0, "F(2,3)")
-                roof["executed_tflops"] = round(ach * fac, 2)
-                roof["executed_frac"] = round(ach * fac / F32_MFMA_PEAK_TFLOPS, 4)
-                roof["note"] = (f"Winograd {what} along W: {fac:.3f} of the algorithmic multiply-adds are executed on the fp32 MFMA pipe; "
-                                "achieved/frac are algorithmic (can exceed the pipe's peak), executed_* is what the pipe sustains")
+                    "algorithm": what, "executed_over_algorithmic": round(fac, 4),
+                    "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak_tflops, 4),
+                    "probe": "HIP events around every conv/wgrad launch of the first timed step, on the launching stream",
+                    "conv_time_share_of_probed_step": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4),
+                    "by_kernel": {k: {"launches": v["n"], "ms": round(v["ms"], 3),
+                                      "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                  for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args.res_blocks, args.workload)
@@ -270,7 +299,9 @@ def main():
                                    f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
                                                            if args.workload == "gan" else ", L1 + Adam"),
                        "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
-                       "generator_train_gflop_per_image": 971.4},
+                       "generator_train_gflop_per_image": 971.4,
+                       "inputs": "the same synthetic batch every step (resident in HBM); tools/soak.py with a fresh batch per "
+                                 "iteration measures the same ms/iter, and the d_threshold gate stays open on it"},
             "roofline": roof, "cpu_baseline": cpu, "split_bf16_mode": alt, "full_size_parity": parity,
         }
         print(json.dumps(out), flush=True)

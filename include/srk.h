@@ -123,6 +123,9 @@ int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* a, size_t* bytes);
  * pixel-splits, so the partial-sum traffic stays small).  The workspace of args[0] is used for all. */
 int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void* stream);
 int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_t* bytes);
+/* Measurement aid: writes the name (as rocprofv3 prints it) of the main kernel srk_conv3x3_wgrad_batched dispatches to
+ * for these arguments into buf (NUL-terminated, truncated to len).  Launches nothing. */
+int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, char* buf, size_t len);
 
 /* Weight packing (OIHW fp32 -> MFMA-fragment order).  One launch packs a whole table.
  * Destination layout for a conv with K input channels and M outputs, Mp = round_up(M, 32):

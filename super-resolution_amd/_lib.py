@@ -16,7 +16,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
-    "srk_conv3x3_wgrad_batched_workspace", "srk_pack_plan", "srk_pack_weights",
+    "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
@@ -89,6 +89,7 @@ def lib():
         L.srk_conv3x3_wgrad_workspace.argtypes = [C.POINTER(WgradArgs), C.POINTER(C.c_size_t)]
         L.srk_conv3x3_wgrad_batched.argtypes = [C.POINTER(WgradArgs), C.c_int, _fp]
         L.srk_conv3x3_wgrad_batched_workspace.argtypes = [C.POINTER(WgradArgs), C.c_int, C.POINTER(C.c_size_t)]
+        L.srk_conv3x3_wgrad_kernel_name.argtypes = [C.POINTER(WgradArgs), C.c_int, C.c_char_p, C.c_size_t]
         L.srk_pack_plan.argtypes = [C.POINTER(PackEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_pack_weights.argtypes = [_fp, C.c_int, C.c_int64, _fp]
         L.srk_pack_weights_bf16x3.argtypes = [_fp, C.c_int, C.c_int64, _fp]
@@ -235,6 +236,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+def _wgrad_kernel_name(arr, n) -> str:
+    """Kernel the C side dispatches this weight-gradient launch to (srk_conv3x3_wgrad_kernel_name: the rules live there)."""
+    buf = C.create_string_buffer(96)
+    check(lib().srk_conv3x3_wgrad_kernel_name(arr, n, buf, 96), "srk_conv3x3_wgrad_kernel_name")
+    return buf.value.decode()
+
+
 def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
                   scale=1.0, accumulate=False, in_slope=1.0, precision=0):
     a = WgradArgs()
@@ -249,7 +257,7 @@ def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, C
     ws = _workspace(nbytes.value, x.t.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket(f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce", 2.0 * N * OH * OW * Cout * Cin * 9)
+        e0, e1 = KernelTimer.bracket(_wgrad_kernel_name(C.byref(a), 1) + "+reduce", 2.0 * N * OH * OW * Cout * Cin * 9)
         e0.record()
         check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
         e1.record()
@@ -277,7 +285,7 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
     ws = _workspace(nbytes.value, problems[0]["x"].t.device)
     arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket((f"wgrad_bf16x3_kernel<{dy_mode}, {3 if precision == 1 else 1}>+reduce" if precision in (1, 2) else f"wgrad_f32_kernel<{stride}, {dy_mode}>+reduce"), flops)
+        e0, e1 = KernelTimer.bracket(_wgrad_kernel_name(arr, n) + "+reduce", flops)
         e0.record()
         check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
         e1.record()

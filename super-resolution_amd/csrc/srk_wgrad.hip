@@ -23,6 +23,7 @@
 // Mirrors the autograd weight/bias gradient of nn.Conv2d at /root/reference/models.py:19,63,67,87,97,99,
 // 142,144,168.
 #include "srk_internal.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1120,6 +1121,35 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
   }
   if (a0.stride == 1) return vec ? launch<1, SRK_IN_PLAIN, true>(B, part, pbias, st) : launch<1, SRK_IN_PLAIN, false>(B, part, pbias, st);
   return vec ? launch<2, SRK_IN_PLAIN, true>(B, part, pbias, st) : launch<2, SRK_IN_PLAIN, false>(B, part, pbias, st);
+}
+
+// Name (as rocprofv3 prints it) of the main kernel srk_conv3x3_wgrad_batched dispatches to for these arguments: the
+// measurement harness attributes its per-launch event times with it, so the dispatch rules live in this file only.
+extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, char* buf, size_t len) {
+  if (!buf || len < 8) return SRK_ERR_BAD_ARG;
+  WBatch B;
+  int rc = build_batch(args, n, B);
+  if (rc) return rc;
+  const srk_wgrad_args& a0 = args[0];
+  if (use_c1(B)) { snprintf(buf, len, "wgrad_c1_kernel<%d>", a0.stride); return SRK_OK; }
+  bool vec = true;
+  for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
+  if (a0.precision == 1 || a0.precision == 2) { snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d>", a0.dy_mode, a0.precision == 1 ? 3 : 1); return SRK_OK; }
+  if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
+  int ksp = 1;
+  if (a0.dy_mode == SRK_IN_PLAIN) {
+    bool all4 = true, all2 = true;
+    for (int i = 0; i < B.n_prob; ++i) {
+      const bool sa = B.prob[i].Cout <= 32, sb = B.prob[i].Cin <= 32;
+      all4 = all4 && sa && sb;
+      all2 = all2 && (sa || sb);
+    }
+    ksp = all4 ? 4 : (all2 ? 2 : 1);
+    const char* e = getenv("SRK_WGRAD_KSPLIT");
+    if (e && !atoi(e)) ksp = 1;
+  }
+  snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %s, %d>", a0.stride, a0.dy_mode, vec ? "true" : "false", ksp);
+  return SRK_OK;
 }
 
 extern "C" int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* pa, size_t* bytes) {

@@ -116,6 +116,12 @@ def _set_binedges(st, opt, nnz, info):
     below which 90 % of them lie, k-means cluster centres (sklearn, random_state=0) as bin centres.  Host-side, once."""
     from sklearn.cluster import KMeans
     nnz = np.array(nnz)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # every rank saw only its shard of the warm-up batches: pool the values (rank order) so that all replicas train with
+        # the SAME bin edges, the ones a single process on the whole batches would have found and the ones info.json records
+        parts = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(parts, nnz)
+        nnz = np.concatenate(parts)
     for k in range(2):
         if st.lambdas[k] > 0:
             p = [1, opt.scaling_power][k]
@@ -266,7 +272,8 @@ def train(opt, **kwargs):
             do_d = (i == opt.warmup_batches) or (batches_done % opt.update_d == 0)
             out = st.gan_step(imgs_lr, imgs_hr, update_g=do_g, update_d=do_d)
             vals = st.loss_scalars(out)                      # one host sync for the whole report
-            if any(v != v for v in (vals["d_loss_def"], vals["d_loss_pow"], vals["g_loss"])):
+            # esrgan.py:645-648; under data parallelism `nan_probe` is the all-reduced flag: every rank raises together
+            if any(v != v for v in (vals["d_loss_def"], vals["d_loss_pow"], vals["g_loss"], vals["nan_probe"])):
                 save_info()
                 raise ValueError("loss is NaN\n[Batch %d] [D def: %e, pow: %e] [G loss: %f]" %
                                  (i, vals["d_loss_def"], vals["d_loss_pow"], vals["g_loss"]))

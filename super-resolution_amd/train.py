@@ -131,11 +131,13 @@ class Stepper:
         vec = torch.stack([d.get(0, z).reshape(()), d.get(1, z).reshape(()), out["g_loss"].reshape(()), g(0, "tot"), g(1, "tot"),
                            g(0, "adv"), g(1, "adv"), g(0, "pixel"), g(1, "pixel"), g(0, "lr"), g(1, "lr"),
                            g(0, "hist"), g(1, "hist"), g(0, "nnz"), g(1, "nnz"), g(0, "mask"), g(1, "mask"),
-                           g(0, "hit"), g(1, "hit")]).tolist()
+                           g(0, "hit"), g(1, "hit"),
+                           (out["nan_probe"].reshape(()) if out.get("nan_probe") is not None else z)]).tolist()
         names = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
                  'pixel_loss_pow', 'lr_loss', 'lr_loss_pow', 'hist_loss', 'hist_loss_pow', 'nnz_loss', 'nnz_loss_pow',
                  'mask_loss', 'mask_loss_pow', 'hit_loss', 'hit_loss_pow']
         out_d = dict(zip(names, vec))
+        out_d["nan_probe"] = vec[-1]       # data parallel: sum of all ranks' losses (NaN on every rank if any rank's is); else 0
         for name in ('wasser_loss', 'wasser_loss_pow', 'wasser_dist', 'wasser_dist_pow'):   # heads this build does not implement
             out_d[name] = 0.0
         return out_d
@@ -266,17 +268,27 @@ class Stepper:
         ground_truth_lr = [imgs_lr, imgs_lr ** self.scaling_power]
         # ---- discriminators (esrgan.py:561-626); they see the pre-update generator output
         loss_D_tot = {}
+        nan_probe = None
+        self.last_gate = {}
         for k, D in (self.discriminators.items() if update_d else ()):
             self.optimizer_D[k].zero_grad(set_to_none=True)
             loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
                                            cond=ground_truth_lr[k])
             loss_D.backward()
             self._sync_grads(D)
-            gate = loss_D.detach()
-            if self.exact_dp:
-                gate = _AllReduceMean.apply(gate)      # every rank must take the same branch
+            gate = loss_D.detach().reshape(1)
+            if self.distributed:
+                # Every rank must take the same branch, or the replicas' weights and Adam states drift apart: the
+                # gate is always the mean over ranks (= the single-process loss_D when exact_dp).  The same exchange carries
+                # this rank's generator loss, so a NaN on ANY rank turns the probe NaN on EVERY rank and the guard of
+                # esrgan.py:645-648 fires everywhere in the same iteration instead of leaving the others in a collective.
+                pair = _AllReduceMean.apply(torch.cat([gate, loss_G.detach().reshape(1)]))
+                gate, nan_probe = pair[:1], (pair.sum() if nan_probe is None else nan_probe + pair.sum())
             if gate.item() > self.d_threshold:            # host sync, as in the reference (esrgan.py:623)
                 self.optimizer_D[k].step()
+            self.last_gate[k] = gate
             loss_D_tot[k] = loss_D.detach()
-        self.last = {"g_loss": loss_G.detach(), "d_loss": loss_D_tot, "parts": parts}
+        if self.distributed and nan_probe is None:        # no discriminator ran this iteration: exchange the probe on its own
+            nan_probe = _AllReduceMean.apply(loss_G.detach().reshape(1)).sum()
+        self.last = {"g_loss": loss_G.detach(), "d_loss": loss_D_tot, "parts": parts, "nan_probe": nan_probe}
         return self.last
