@@ -897,7 +897,8 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       out[tq][0][4 * sx + 2] = s12 + 4.f * s34;
       out[tq][0][4 * sx + 3] = (d12 + 8.f * d34) + m5;
     }
-  conv_epilogue<32, 4>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
+  __builtin_amdgcn_sched_barrier(0);     // keep the epilogue's 32 prefetch loads (128 VGPRs) behind the output transform
+  conv_epilogue<32, 4, false, 16>(a, out, smem, n, oh0, ow0, n0 + 32 * nh, wg, lane, wv);
   SRK_STAMP_AT(4);
 }
 
@@ -978,6 +979,15 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
   // the kernels address one input image through a 32-bit buffer resource (out-of-range lanes read 0)
   if (a.H > 0 && a.W > 0 && a.x_ldc > 0 &&
       (long)a.H * a.W * a.x_ldc * 4 * (a.in_mode == SRK_IN_UNSHUFFLE ? 4 : 1) > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
+  // the epilogue addresses one output image (and the same image of r1 / r2 / mask) through a 32-bit buffer resource
+  if (a.OH > 0 && a.OW > 0) {
+    const long px = (long)a.OH * a.OW * (a.ps_out ? 4 : 1);
+    int ld = a.y_ldc;
+    if (a.r1 && a.r1_ldc > ld) ld = a.r1_ldc;
+    if (a.r2 && a.r2_ldc > ld) ld = a.r2_ldc;
+    if (a.mask && a.m_ldc > ld) ld = a.m_ldc;
+    if (px * ld * 4 > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
+  }
   if (a.wp_format == 1 || a.wp_format == 2) {
     if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return SRK_ERR_BAD_ARG;
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
