@@ -282,7 +282,7 @@ def main():
                     "conv_time_share_of_probed_step": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4),
                     "by_kernel": {k: {"launches": v["n"], "ms": round(v["ms"], 3),
                                       "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                  for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+                                  for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])[:(40 if L.KernelTimer.detail else 6)]}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args.res_blocks, args.workload)

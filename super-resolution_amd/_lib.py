@@ -152,6 +152,7 @@ class KernelTimer:
     roofline leg).  Off by default; when on, every srk_conv3x3 / srk_conv3x3_wgrad call is bracketed by two
     events and attributed to the kernel template the C side dispatches to (same names rocprofv3 reports)."""
     active = False
+    detail = os.environ.get("SRK_KT_DETAIL", "0") == "1"
     records = []
 
     @classmethod
@@ -216,7 +217,10 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, C
     if mask is not None:
         a.mask, a.m_ldc, a.m_coff, a.mask_slope = mask.t.data_ptr(), mask.ldc, mask.coff, mask_slope
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket(_conv_kernel_name(a), 2.0 * N * OH * OW * Cout * Cin * 9)
+        name = _conv_kernel_name(a)
+        if KernelTimer.detail:       # diagnostic split by problem shape and by what the fused epilogue reads
+            name += f" Cin={Cin} Cout={Cout} {OH}x{OW} epi={'b' if bias is not None else ''}{'r' if r1 is not None else ''}{'R' if r2 is not None else ''}{'m' if mask is not None else ''}"
+        e0, e1 = KernelTimer.bracket(name, 2.0 * N * OH * OW * Cout * Cin * 9)
         e0.record()
         check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
         e1.record()

@@ -17,8 +17,15 @@ for ci in (64, 320):
     b = torch.zeros(F, device="cuda")
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
     lib.srk_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    EPI = os.environ.get("EPI", "bias")       # bias | mask | res2: what the fused epilogue reads besides the accumulators
+    mk = torch.randn(N, H, W, 320, device="cuda"); r2 = torch.randn(N, H, W, F, device="cuda")
+    kw = dict(slope=0.01)
+    if EPI == "mask":
+        kw = dict(mask=L.View(mk, 64, F), mask_slope=0.01)
+    elif EPI == "res2":
+        kw = dict(alpha=0.02, r1=L.View(mk, 0, F), beta1=0.1, r2=L.View(r2), beta2=1.0)
     for _ in range(3):
-        L.conv3x3(L.View(buf, 0, ci), wp, b, L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, slope=0.01, wp_format=FMT)
+        L.conv3x3(L.View(buf, 0, ci), wp, (None if EPI == "mask" else b), L.View(out), N=N, H=H, W=W, OH=H, OW=W, Cin=ci, Cout=F, wp_format=FMT, **kw)
     torch.cuda.synchronize()
     nwg = N * 16 if FMT == 3 else N * 8
     s = stamps.cpu().view(-1, 16)[:nwg].double() * 0.01   # us (s_memrealtime, 100 MHz)
