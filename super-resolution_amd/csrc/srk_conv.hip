@@ -34,11 +34,13 @@ extern "C" int srk_debug_set_stamps(void* p) {
 #define SRK_STAMP_AT(k) do { if (threadIdx.x == 0 && g_srk_stamps) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define SRK_CLOCK_AT(k) do { if (threadIdx.x == 0 && g_srk_stamps) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define SRK_SEG_BEGIN() unsigned long long seg_t = __builtin_amdgcn_s_memtime(); unsigned long long seg_sum[6] = {0,0,0,0,0,0}
+#define SRK_SEG_RESET() do { seg_t = __builtin_amdgcn_s_memtime(); } while (0)
 #define SRK_SEG(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_sum[k] += t_ - seg_t; seg_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define SRK_SEG_END() do { if (threadIdx.x == 0 && g_srk_stamps) for (int k_ = 0; k_ < 6; ++k_) g_srk_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + k_] = seg_sum[k_]; } while (0)
+#define SRK_SEG_END() do { if ((threadIdx.x == 0 || threadIdx.x == 256) && g_srk_stamps) for (int k_ = 0; k_ < 6; ++k_) g_srk_stamps[(threadIdx.x ? 4096 * 16 : 0) + (blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + k_] = seg_sum[k_]; } while (0)
 #else
 #define SRK_SEG_BEGIN() do { } while (0)
 #define SRK_SEG(k) do { } while (0)
+#define SRK_SEG_RESET() do { } while (0)
 #define SRK_SEG_END() do { } while (0)
 #define SRK_CLOCK_AT(k) do { } while (0)
 #define SRK_STAMP_AT(k) do { } while (0)
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
   SRK_STAMP_AT(1);
   __syncthreads();                               // chunk 0 staged by the loader
   SRK_STAMP_AT(2);
+  SRK_CLOCK_AT(5);
   ld_row(0, 0, 0);
   transform(0);
   int q = 0;
@@ -667,6 +670,7 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
     chunk(q + 1, std::integral_constant<int, 1>{});
   }
   if (q < nq) chunk(q, std::integral_constant<int, 0>{});
+  SRK_CLOCK_AT(6);
   SRK_STAMP_AT(3);
   // output transform + register renaming into conv_epilogue's layout: source register 4*tq + s holds column pair
   // c = cmap(4*hl + s) of row tq; destination tile m = tq>>1, register 4*(2*(tq&1) + (s>>1)) + 2*(s&1) + e.
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
-  unsigned vo[NPW];
+  unsigned vo[4];
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
@@ -763,12 +767,9 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       }
       vo[j] = v;
     }
-#pragma unroll
-    for (int j = 3; j < NPW; ++j) {
-      const int wi = (j < 7 ? wv + 8 * (j - 3) : 32 + wv) * 64 + lane;
-      const int th = wi / BN, co = wi - th * BN;
-      vo[j] = (wi < NW4 && n0 + co < CoutP) ? (unsigned)((th * CoutP + n0 + co) * 16) : OOB;
-    }
+    // weight instruction i covers packed row th = i (BN = 64 lanes = 64 output channels): the lane part of the offset is
+    // the same for every piece, the row goes into the scalar offset
+    vo[3] = (n0 + lane < CoutP) ? (unsigned)((n0 + lane) * 16) : OOB;
   }
   const bool low4 = wv < 4;
   auto piece = [&](int q, int b, auto jc) {
@@ -786,9 +787,9 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       const int i = j < 2 ? wv + 8 * j : 16 + wv;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 64), 16, vo[j], xso, 0, 0);
     } else {
-      const unsigned wso = (unsigned)(q * 36 * CoutP * 16);
       const int i = j < 7 ? wv + 8 * (j - 3) : 32 + wv;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + NXP + i * 64), 16, vo[j], wso, 0, 0);
+      const unsigned wso = (unsigned)((q * 36 + i) * CoutP * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + NXP + i * 64), 16, vo[3], wso, 0, 0);
     }
   };
   static_assert(NXI == 20 && NWI == 36, "piece schedule assumes 20 halo + 36 weight DMA instructions");
@@ -806,14 +807,17 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const int abase = (trow * IW + 4 * tcol) * 2 + hl;
   const int wbase = NXP + hl * BN + 32 * nh + l32;
   f32x4 dn[6], V[2][6], Bv[2][6];
-  auto ld_row = [&](int b, int r, int par) {
+  auto ld_d = [&](int b, int r) {
     const f32x4* xb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + abase + r * IW * 2;
-    const f32x4* wb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + wbase + (6 * r) * 2 * BN;
 #pragma unroll
     for (int j = 0; j < 6; ++j) dn[j] = xb[2 * j];
+  };
+  auto ld_w = [&](int b, int r, int par) {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(smem + b * BUF4) + wbase + (6 * r) * 2 * BN;
 #pragma unroll
     for (int p = 0; p < 6; ++p) Bv[par][p] = wb[p * 2 * BN];
   };
+  auto ld_row = [&](int b, int r, int par) { ld_d(b, r); ld_w(b, r, par); };
   auto transform = [&](int par) {
     const f32x4 t1 = dn[1] + dn[2], t2 = dn[4] + dn[3], t3 = dn[1] - dn[2], t4 = dn[4] - dn[3];
     const f32x4 t5 = dn[4] - dn[2], t6 = dn[3] - dn[1];
@@ -840,30 +844,86 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       }
     }
   };
+  SRK_SEG_BEGIN();
   using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using I5 = std::integral_constant<int, 5>;
   // chunk q sits in buffer b.  Chunk q+1 streams into b^1: its pieces 0-1 were issued behind the previous chunk's last
   // row, 2-7 go behind rows 0 and 1 here; after the barrier b is free and chunk q+2's pieces 0-1 go behind row 2.
-  auto chunk = [&](int q, auto P0c) {
+  //
+  // The two waves of a SIMD (wv and wv + 4: same rows, the two channel halves) leave every barrier together.  If both ran the
+  // same order "24 MFMAs, then the next row's transform", their transforms (~60 VALU instructions each) would coincide and
+  // the matrix pipe would idle three times per chunk.  So the second wave (ROLE_B) runs every (MFMA row, transform) pair the
+  // other way round: it transforms while its partner issues MFMAs and the reverse.  Same instructions, same registers; the
+  // offset is in the program order, so barriers do not undo it.
+  auto chunk = [&](int q, auto P0c, auto rolec) {
     constexpr int P0 = decltype(P0c)::value;
+    constexpr bool ROLE_B = decltype(rolec)::value;
     const int b = q & 1;
     const bool more = q + 1 < nq;
-    ld_row(b, 1, P0 ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0, q + 1, b ^ 1, I2{}, I3{});
-    __builtin_amdgcn_sched_barrier(0);
-    transform(P0 ^ 1);
-    ld_row(b, 2, P0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0 ^ 1, q + 1, b ^ 1, I5{}, I3{});
-    __builtin_amdgcn_sched_barrier(0);
-    transform(P0);
-    __syncthreads();                             // buffer b consumed (row 2 in registers); chunk q+1 landed in b^1
-    if (more) ld_row(b ^ 1, 0, P0 ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_row(P0, q + 2, b, I0{}, I2{});          // tap row 2
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) transform(P0 ^ 1);
+    if constexpr (!ROLE_B) {
+      ld_row(b, 1, P0 ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(0);
+      mfma_row(P0, q + 1, b ^ 1, I2{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+      transform(P0 ^ 1);
+      SRK_SEG(2);
+      ld_row(b, 2, P0);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(0);
+      mfma_row(P0 ^ 1, q + 1, b ^ 1, I5{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+      transform(P0);
+      SRK_SEG(2);
+      __syncthreads();                             // buffer b consumed (row 2 in registers); chunk q+1 landed in b^1
+      SRK_SEG(3);
+      if (more) ld_row(b ^ 1, 0, P0 ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(0);
+      mfma_row(P0, q + 2, b, I0{}, I2{});          // tap row 2
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+      if (more) transform(P0 ^ 1);
+      SRK_SEG(2);
+    } else {
+      // raw row -> transform -> only then that row's weights (their registers and the raw row are never live together)
+      ld_d(b, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(0);
+      transform(P0 ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(2);
+      ld_w(b, 1, P0 ^ 1);
+      mfma_row(P0, q + 1, b ^ 1, I2{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+      ld_d(b, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(0);
+      transform(P0);
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(2);
+      ld_w(b, 2, P0);
+      mfma_row(P0 ^ 1, q + 1, b ^ 1, I5{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+      __syncthreads();
+      SRK_SEG(3);
+      if (more) {
+        ld_d(b ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SRK_SEG(0);
+        transform(P0 ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        SRK_SEG(2);
+        ld_w(b ^ 1, 0, P0 ^ 1);
+      }
+      mfma_row(P0, q + 2, b, I0{}, I2{});
+      __builtin_amdgcn_sched_barrier(0);
+      SRK_SEG(1);
+    }
   };
   piece(0, 0, std::integral_constant<int, 0>{}); piece(0, 0, std::integral_constant<int, 1>{});
   piece(0, 0, std::integral_constant<int, 2>{}); piece(0, 0, std::integral_constant<int, 3>{});
@@ -874,14 +934,27 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   SRK_STAMP_AT(1);
   __syncthreads();
   SRK_STAMP_AT(2);
+  SRK_CLOCK_AT(5);
   ld_row(0, 0, 0);
   transform(0);
-  int q = 0;
-  for (; q + 1 < nq; q += 2) {
-    chunk(q, std::integral_constant<int, 0>{});
-    chunk(q + 1, std::integral_constant<int, 1>{});
+  SRK_SEG_RESET();
+#define SRK_W4_LOOP(ROLE)                                                   \
+  {                                                                         \
+    int q = 0;                                                              \
+    for (; q + 1 < nq; q += 2) {                                            \
+      chunk(q, std::integral_constant<int, 0>{}, ROLE{});                   \
+      chunk(q + 1, std::integral_constant<int, 1>{}, ROLE{});               \
+    }                                                                       \
+    if (q < nq) chunk(q, std::integral_constant<int, 0>{}, ROLE{});         \
   }
-  if (q < nq) chunk(q, std::integral_constant<int, 0>{});
+#ifdef SRK_WINO4_NO_ROLES
+  SRK_W4_LOOP(std::false_type)
+#else
+  if (nh == 0) SRK_W4_LOOP(std::false_type) else SRK_W4_LOOP(std::true_type)
+#endif
+#undef SRK_W4_LOOP
+  SRK_SEG_END();
+  SRK_CLOCK_AT(6);
   SRK_STAMP_AT(3);
   // output transform: source register 4q+s -> epilogue tile q, registers 4s .. 4s+3 (columns 4*tcol .. +3)
   f32x16 out[4][1];

@@ -19,3 +19,4 @@ static inline int srk_div_up(int v, int m) { return (v + m - 1) / m; }
     hipError_t e__ = hipGetLastError();                      \
     if (e__ != hipSuccess) return SRK_ERR_LAUNCH;            \
   } while (0)
+

@@ -320,6 +320,9 @@ __device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
 }
 
+#ifndef WW_PRIO
+#define WW_PRIO 0
+#endif
 constexpr int WW_THREADS = 512;
 constexpr int WW_TILE_FLOATS = WGeo<1>::TP * 64 + WGeo<1>::NHP * 64;     // 11008 floats = 44,032 B per buffer
 
@@ -444,6 +447,9 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
   }
   __syncthreads();
   WST_DECL();
+#if WW_PRIO == 1
+  if (ks == 1) __builtin_amdgcn_s_setprio(1);
+#endif
   int b = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
     const bool more = tile + 2 < t_end;
@@ -490,6 +496,11 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const bool nxt = kk + 1 < 8;
+#if WW_PRIO == 2
+        if (((kk & 1) != 0) == (ks != 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif WW_PRIO == 3
+        if (((kk >> 1) & 1) == ks) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (nxt) ld_k(kk + 1);
         __builtin_amdgcn_sched_barrier(0);

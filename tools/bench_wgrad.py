@@ -16,7 +16,8 @@ for k in range(1, 6):
     probs.append(dict(x=L.View(buf, 0, ci), dy=L.View(E, (5 - k) * F, F), dw=torch.empty(F, ci, 3, 3, device="cuda"),
                       db=torch.empty(F, device="cuda"), Cin=ci, Cout=F))
     fl += 2.0 * N * H * W * F * ci * 9
-dt = timeit(lambda: L.conv3x3_wgrad_batched(probs, N=N, H=H, W=W, OH=H, OW=W, precision=prec), iters=30)
+IT = int(os.environ.get("ITERS", 30))
+dt = timeit(lambda: L.conv3x3_wgrad_batched(probs, N=N, H=H, W=W, OH=H, OW=W, precision=prec), iters=IT, warm=max(3, IT // 4))
 print(f"batched DRB wgrad (5 convs, N={N}): {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF/s")
 for k in (1, 5):
     p = probs[k - 1]
