@@ -123,6 +123,12 @@ int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* a, size_t* bytes);
  * pixel-splits, so the partial-sum traffic stays small).  The workspace of args[0] is used for all. */
 int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void* stream);
 int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_t* bytes);
+/* Test aid: routing of convolutions with <= 4 channels on one side to the HBM-bound kernels of srk_conv_small.hip:
+ * 0 = never, 1 = when their 16x16 tiles fill the chip (default), 2 = whenever the shape allows (small parity cases). */
+int srk_debug_set_conv_small(int mode);
+/* Measurement aid: writes the name (as rocprofv3 prints it) of the kernel srk_conv3x3 dispatches to for these arguments into
+ * buf (NUL-terminated, truncated to len).  Launches nothing. */
+int srk_conv3x3_kernel_name(const srk_conv_args* args, char* buf, size_t len);
 /* Measurement aid: writes the name (as rocprofv3 prints it) of the main kernel srk_conv3x3_wgrad_batched dispatches to
  * for these arguments into buf (NUL-terminated, truncated to len).  Launches nothing. */
 int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, char* buf, size_t len);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
@@ -85,6 +85,8 @@ def lib():
         L.srk_packed_floats_wino4.restype = C.c_size_t
         L.srk_packed_floats_wino4.argtypes = [C.c_int, C.c_int]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
+        L.srk_debug_set_conv_small.argtypes = [C.c_int]
+        L.srk_conv3x3_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]
         L.srk_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), _fp]
         L.srk_conv3x3_wgrad_workspace.argtypes = [C.POINTER(WgradArgs), C.POINTER(C.c_size_t)]
         L.srk_conv3x3_wgrad_batched.argtypes = [C.POINTER(WgradArgs), C.c_int, _fp]
@@ -181,20 +183,10 @@ class KernelTimer:
 
 
 def _conv_kernel_name(a) -> str:
-    """Mirror of the dispatch in srk_conv.hip (srk_conv3x3)."""
-    if a.wp_format in (1, 2):
-        return f"conv3x3_bf16x3_kernel<{a.in_mode}, {3 if a.wp_format == 1 else 1}>"
-    if a.wp_format == 3:
-        return f"conv3x3_f32_wino_kernel<{a.in_mode}>"
-    if a.wp_format == 5:
-        return f"conv3x3_f32_wino4_kernel<{a.in_mode}>"
-    vec = (a.Cin % 8 == 0) and (a.x_ldc % 4 == 0) and (a.x_coff % 4 == 0) and (a.x % 16 == 0)
-    bn = 64 if (a.stride == 1 and a.Cout > 32) else 32
-    mt = 2 if (a.stride == 1 and (a.OH + 15) // 16 * 16 == (a.OH + 7) // 8 * 8) else 1
-    if a.stride == 1 and vec and mt == 2 and bn == 64 and a.in_mode != IN_ZERO_UPSAMPLE and os.environ.get("SRK_CONV_LW", "1") != "0":
-        return f"conv3x3_f32_lw_kernel<{bn}, {a.in_mode}>"
-    dma = False   # the DMA staging variant is compiled out of the dispatch (slower on gfx950, see srk_conv.hip)
-    return f"conv3x3_f32_kernel<{bn}, {a.stride}, {a.in_mode}, {'true' if vec else 'false'}, {mt}, {'true' if dma else 'false'}>"
+    """Kernel the C side dispatches this conv launch to (srk_conv3x3_kernel_name: the rules live in srk_conv.hip only)."""
+    buf = C.create_string_buffer(96)
+    check(lib().srk_conv3x3_kernel_name(C.byref(a), buf, 96), "srk_conv3x3_kernel_name")
+    return buf.value.decode()
 
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,

@@ -531,3 +531,51 @@ def test_wino_rejects_unsupported(U):
     y2 = torch.zeros(1, 4, 4, 64, device="cuda")
     with pytest.raises(RuntimeError):
         L.conv3x3(L.View(x), wp, None, L.View(y2), N=1, H=8, W=8, OH=4, OW=4, Cin=8, Cout=64, stride=2, wp_format=3)
+
+
+@pytest.fixture
+def force_small(U):
+    """Route every eligible conv to the HBM-bound small-channel kernels (srk_conv_small.hip), whatever the tile count."""
+    U.L.lib().srk_debug_set_conv_small(2)
+    yield
+    U.L.lib().srk_debug_set_conv_small(1)
+
+
+@pytest.mark.parametrize("ci,co,h,w,n", [(1, 16, 32, 32, 2), (1, 64, 19, 37, 1), (3, 16, 16, 16, 2), (3, 64, 33, 18, 1), (2, 8, 9, 7, 1), (4, 32, 20, 20, 1),
+                                         (16, 1, 32, 32, 2), (64, 1, 21, 35, 1), (64, 3, 16, 48, 1), (8, 2, 9, 9, 1), (40, 4, 17, 16, 1), (16, 1, 256, 256, 1)])
+def test_small_channel_kernels_fwd(U, force_small, ci, co, h, w, n):
+    """conv3x3_cin_small_kernel (Cin <= 4) / conv3x3_cout_small_kernel (Cout <= 4): bias + LeakyReLU epilogue, ragged edges,
+    against the CPU oracle (models.py:63,99,142,168)."""
+    L = U.L
+    x = _rand((n, ci, h, w), 41)
+    wt = _rand((co, ci, 3, 3), 42, 1.0 / np.sqrt(9 * ci))
+    b = _rand((co,), 43, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b), 0.2)
+    wp, _ = U.pack_fwd(wt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda")
+    a = L.ConvArgs(); a.wp_format = 0; a.stride = 1; a.in_mode = 0; a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout = n, h, w, h, w, ci, co
+    xd = U.nhwc(x); a.x, a.x_ldc, a.x_coff = xd.data_ptr(), ci, 0; a.wp = wp.data_ptr(); a.y, a.y_ldc, a.y_coff = y.data_ptr(), co, 0
+    assert ("cin_small" if ci <= 4 else "cout_small") in L._conv_kernel_name(a)
+    L.conv3x3(L.View(xd), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.2)
+    assert U.rel_err(U.nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("ci,co", [(1, 16), (3, 8), (16, 1), (24, 3)])
+def test_small_channel_kernels_views_and_fused_epilogue(U, force_small, ci, co):
+    """channel-slice views on both sides, input LeakyReLU (the discriminator's pre-activation chain), alpha, two residuals and
+    the LeakyReLU' output mask -- the same fused epilogue as the MFMA kernels."""
+    L = U.L
+    n, h, w = 2, 18, 21
+    xfull = _rand((n, ci + 8, h, w), 44)
+    wt = _rand((co, ci, 3, 3), 45, 0.2)
+    b = _rand((co,), 46, 0.1)
+    r1, r2, m = _rand((n, co, h, w), 47), _rand((n, co, h, w), 48), _rand((n, co, h, w), 49)
+    ref = 0.3 * O.conv3x3(O.lrelu(xfull[:, 4:4 + ci], 0.2), wt, b) + 0.5 * r1 - 1.5 * r2
+    ref = O.lrelu(ref, 0.1) * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
+    buf = U.nhwc(xfull)
+    out = torch.zeros(n, h, w, co + 8, device="cuda")
+    wp, _ = U.pack_fwd(wt)
+    L.conv3x3(L.View(buf, 4, ci), wp, b.cuda(), L.View(out, 4, co), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, in_slope=0.2, alpha=0.3, slope=0.1,
+              r1=L.View(U.nhwc(r1)), beta1=0.5, r2=L.View(U.nhwc(r2, ldc=co + 4, coff=4), 4, co), beta2=-1.5, mask=L.View(U.nhwc(m)), mask_slope=0.01)
+    assert U.rel_err(U.nchw(out, 4, co), ref) < TOL
+    assert out[..., :4].abs().max().item() == 0.0 and out[..., 4 + co:].abs().max().item() == 0.0
