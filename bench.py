@@ -10,6 +10,10 @@ GeneratorRRDB(1, 64, 23, num_upsample=2)):
            (BASELINE configs[2]; configs[3] = the same on 8 GPUs)
   g_only : the reference's warm-up iteration (esrgan.py:416-439): G forward, L1, backward, Adam, batch 16/GPU
            (BASELINE configs[1])
+  c4     : BASELINE configs[4]: the same warm-up iteration on GeneratorRRDB(3, 64, 23, num_upsample=2), 3x128x128 -> 3x512x512
+           photographic-style images, batch 8/GPU, reduced-precision MFMA path.  configs[4] says fp16; this build's
+           reduced-precision kernels take bf16 operands (fp32 accumulate, fp32 master weights and activations in HBM):
+           same MFMA rate as fp16 on gfx950 (2.5 PFLOP/s dense), wider exponent, no loss scaling -- `dtype` says so.
 Inputs are generated on the GPU before the timed region.  For N > 1 launch with
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: one process per GPU, weak scaling
 (fixed per-GPU batch), gradients averaged with RCCL all-reduce overlapped with the backward pass.
@@ -31,6 +35,11 @@ sys.path.insert(0, ROOT)
 HR = 256
 FACTOR = 4
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+# per workload: image channels, HR extent, per-GPU batch, the Stepper's workload, default precision
+WORKLOADS = {"gan": dict(channels=1, hr=256, batch=32, step="gan", precision="f32"),
+             "g_only": dict(channels=1, hr=256, batch=16, step="g_only", precision="f32"),
+             "c4": dict(channels=3, hr=512, batch=8, step="g_only", precision="bf16")}
 
 
 def parse():
@@ -38,24 +47,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("SRK_WORKLOAD", "gan"), choices=["g_only", "gan"],
-                    help="gan = BASELINE.json's metric (full G+D iteration, configs[2]); g_only = warm-up iteration (configs[1])")
+    ap.add_argument("--workload", default=os.environ.get("SRK_WORKLOAD", "gan"), choices=["g_only", "gan", "c4"],
+                    help="gan = BASELINE.json's metric (full G+D iteration, configs[2]); g_only = warm-up iteration (configs[1]); "
+                         "c4 = configs[4] (3-channel 128->512, bf16 MFMA path, batch 8)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
     ap.add_argument("--res-blocks", type=int, default=23)
-    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
-                    help="f32 (default, headline): exact-fp32 MFMA everywhere.  bf16x3: opt-in split-bf16 MFMA mode")
+    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", ""), choices=["", "f32", "bf16x3", "bf16"],
+                    help="f32 (default for gan / g_only, the headline): exact-fp32 MFMA everywhere.  bf16x3: opt-in split-bf16 MFMA "
+                         "mode.  bf16 (default for c4): bf16 MFMA operands, fp32 accumulate")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra opt-in bf16x3 measurement and the full-size parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket conv launches with events")
     return ap.parse_args()
 
 
-def synth_batch(n, device, seed):
-    """hr = 10*U(0,1)*Bernoulli(0.1); lr = SumPool2d(4)(hr) (datasets.py:227,247)."""
+def synth_batch(n, device, seed, channels=1, hr_px=HR):
+    """SURVEY 8(d).  Jets (1 channel): hr = 10*U(0,1)*Bernoulli(0.1); lr = SumPool2d(4)(hr) (datasets.py:227,247).
+    Photographic config (3 channels): hr = U(0,1), lr = avg_pool(4)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    hr = 10.0 * torch.rand(n, 1, HR, HR, generator=g) * (torch.rand(n, 1, HR, HR, generator=g) < 0.1).float()
-    hr = hr.to(device)
-    lr = 16.0 * torch.nn.functional.avg_pool2d(hr, FACTOR)
+    if channels == 1:
+        hr = 10.0 * torch.rand(n, 1, hr_px, hr_px, generator=g) * (torch.rand(n, 1, hr_px, hr_px, generator=g) < 0.1).float()
+        hr = hr.to(device)
+        lr = 16.0 * torch.nn.functional.avg_pool2d(hr, FACTOR)
+    else:
+        hr = torch.rand(n, channels, hr_px, hr_px, generator=g).to(device)
+        lr = torch.nn.functional.avg_pool2d(hr, FACTOR)
     return lr.contiguous(), hr.contiguous()
 
 
@@ -74,17 +90,22 @@ def host_cores():
 
 def cpu_baseline(res_blocks, workload):
     """Times the CPU oracle (a port of the reference's step, oracle/esrgan_oracle.py) on this box's host cores
-    on a bounded sample (batch 4, 1 warm-up + up to 4 timed iterations, ~10-30 s); baseline only."""
+    on a bounded sample (batch 4 jets / batch 1 photographic image, 1 warm-up + up to 4 timed iterations, ~10-30 s); baseline only."""
     from oracle import esrgan_oracle as O
-    n = 4
+    wl = WORKLOADS[workload]
+    ch, hr_px, step = wl["channels"], wl["hr"], wl["step"]
+    n = 4 if ch == 1 else 1
     cores = host_cores()
     torch.set_num_threads(cores)
-    sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
+    sd = O.default_init_generator(0, channels=ch, filters=64, num_res_blocks=res_blocks, num_upsample=2)
     params = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999))
-    lr, hr = O.jet_images(n, 1, HR, HR, 1234, FACTOR)
+    if ch == 1:
+        lr, hr = O.jet_images(n, 1, hr_px, hr_px, 1234, FACTOR)
+    else:
+        lr, hr = [t.cpu() for t in synth_batch(n, "cpu", 1234, ch, hr_px)]
     dsd, optD = [], []
-    if workload == "gan":
+    if step == "gan":
         g = torch.Generator().manual_seed(1)
         for k in range(2):
             d = {}
@@ -98,7 +119,7 @@ def cpu_baseline(res_blocks, workload):
         t0 = time.perf_counter()
         opt.zero_grad()
         y, srs = O.generator_forward(params, lr, res_blocks, 2, 0.2, training=True)
-        if workload == "gan":                         # esrgan.py:457-626 restated (oracle/esrgan_oracle.py)
+        if step == "gan":                             # esrgan.py:457-626 restated (oracle/esrgan_oracle.py)
             lG, _ = O.g_phase_loss([y, srs], hr, lr, dsd, FACTOR)
             lG.backward()
             opt.step()
@@ -117,30 +138,40 @@ def cpu_baseline(res_blocks, workload):
             break
     timed = times[1:]
     dt = sum(timed) / len(timed)
-    return {"value": n * HR * HR / dt, "unit": "HR-px/s", "cores": cores, "kind": "port",
-            "sample": ("full G+D iteration (two patch discriminators, relativistic BCE, gradient penalty, 3x Adam)" if workload == "gan"
+    return {"value": n * hr_px * hr_px / dt, "unit": "HR-px/s", "cores": cores, "kind": "port",
+            "sample": ("full G+D iteration (two patch discriminators, relativistic BCE, gradient penalty, 3x Adam)" if step == "gan"
                        else "G-only step (fwd+L1+bwd+Adam)") +
-                      f" of the same generator, batch {n}, 1 warm-up + {len(timed)} timed iters, {dt*1e3:.0f} ms/iter, torch CPU fp32"}
+                      f" of the same generator, batch {n} of {ch}x{hr_px // FACTOR}x{hr_px // FACTOR}, 1 warm-up + {len(timed)} timed iters, "
+                      f"{dt*1e3:.0f} ms/iter, torch CPU fp32"}
 
 
-def full_size_parity(sr, res_blocks, dev):
-    """Generator forward at BASELINE's full architecture (F=64, R=23, 4x) on 2 jet images, HIP path vs the CPU oracle
-    on identical weights/inputs: max |diff| / max |ref| for the exact-fp32 mode and for the opt-in bf16x3 mode."""
+def full_size_parity(sr, res_blocks, dev, workload):
+    """Generator forward at the workload's full architecture (F=64, R=23, 4x) on 2 jet images (1 photographic image for c4),
+    HIP path vs the CPU fp32 oracle on identical weights/inputs: max |diff| / max |ref| per precision mode, with the tolerance
+    each mode is held to (f32 / bf16x3: BASELINE's 1e-3; bf16 operands: 3e-2, the mixed-precision bar of configs[4])."""
     from oracle import esrgan_oracle as O
-    sd = O.default_init_generator(0, channels=1, filters=64, num_res_blocks=res_blocks, num_upsample=2)
-    lr, hr = O.jet_images(2, 1, HR, HR, 4321, FACTOR)
+    wl = WORKLOADS[workload]
+    ch, hr_px = wl["channels"], wl["hr"]
+    sd = O.default_init_generator(0, channels=ch, filters=64, num_res_blocks=res_blocks, num_upsample=2)
+    if ch == 1:
+        lr, hr = O.jet_images(2, 1, hr_px, hr_px, 4321, FACTOR)
+    else:
+        lr, hr = synth_batch(1, "cpu", 4321, ch, hr_px)
     with torch.no_grad():
         ref, _ = O.generator_forward(sd, lr, res_blocks, 2, 0.2, training=True)
-    gen = sr.GeneratorRRDB(1, filters=64, num_res_blocks=res_blocks, num_upsample=2).to(dev)
+    gen = sr.GeneratorRRDB(ch, filters=64, num_res_blocks=res_blocks, num_upsample=2).to(dev)
     gen.load_state_dict(sd)
     out = {}
-    for mode in ("f32", "bf16x3"):
+    modes = ("f32", "bf16x3") if wl["precision"] == "f32" else ("f32", "bf16x3", "bf16")
+    for mode in modes:
         gen._engine.precision = mode
         with torch.no_grad():
             y = gen(lr.to(dev)).cpu()
         out[mode] = float((y - ref).abs().max() / ref.abs().max())
-    out["tolerance"] = 1e-3
-    out["what"] = "GeneratorRRDB(1,64,%d,num_upsample=2) forward, 2x1x64x64 -> 2x1x256x256, max-abs relative error vs CPU oracle" % res_blocks
+    out["tolerance"] = {"f32": 1e-3, "bf16x3": 1e-3, "bf16": 3e-2}
+    out["ok"] = all(out[m] < out["tolerance"][m] for m in modes)
+    out["what"] = ("GeneratorRRDB(%d,64,%d,num_upsample=2) forward, %s -> %s, max-abs relative error vs the CPU fp32 oracle"
+                   % (ch, res_blocks, "x".join(map(str, lr.shape)), "x".join(map(str, ref.shape))))
     return out
 
 
@@ -192,12 +223,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    batch = args.batch or (16 if args.workload == "g_only" else 32)
+    wl = WORKLOADS[args.workload]
+    precision = args.precision or wl["precision"]
+    hr_px, channels = wl["hr"], wl["channels"]
+    batch = args.batch or wl["batch"]
     torch.manual_seed(0)                                  # identical replicas on every rank
-    stepper = train.Stepper(workload=args.workload, res_blocks=args.res_blocks, device=dev, hr=HR, factor=FACTOR,
+    stepper = train.Stepper(workload=wl["step"], res_blocks=args.res_blocks, device=dev, hr=hr_px, factor=FACTOR, channels=channels,
                             distributed=(world > 1 or force_dist))
-    stepper.generator._engine.precision = args.precision
-    lr_img, hr_img = synth_batch(batch, dev, 1234 + rank)
+    stepper.generator._engine.precision = precision
+    lr_img, hr_img = synth_batch(batch, dev, 1234 + rank, channels, hr_px)
 
     def barrier():
         if dist is not None:
@@ -229,7 +263,7 @@ def main():
 
     # ---- extra, outside the headline: the opt-in split-bf16 mode on the same workload (every rank takes part)
     alt = None
-    if not args.no_alt and args.precision == "f32":
+    if not args.no_alt and precision == "f32":
         stepper.generator._engine.precision = "bf16x3"
         for _ in range(2):
             stepper.step(lr_img, hr_img)
@@ -244,10 +278,10 @@ def main():
         adt = adt.item()
         stepper.generator._engine.precision = "f32"
         alt = {"precision": "bf16x3: fwd/dgrad/wgrad convs as 3 bf16 MFMAs per product (operands split hi+lo, fp32 accumulate); "
-                            "opt-in, NOT the headline", "value": world * batch * HR * HR * args.steps / adt, "unit": "HR-px/s",
+                            "opt-in, NOT the headline", "value": world * batch * hr_px * hr_px * args.steps / adt, "unit": "HR-px/s",
                "ms_per_step": adt / args.steps * 1e3}
     ms = dt / args.steps * 1e3
-    value = world * batch * HR * HR * args.steps / dt
+    value = world * batch * hr_px * hr_px * args.steps / dt
 
     if rank == 0:
         roof = None
@@ -255,7 +289,7 @@ def main():
             dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"])
             name, st = dom
             ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
-            peak_tflops = F32_MFMA_PEAK_TFLOPS
+            peak_tflops = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
@@ -272,6 +306,9 @@ def main():
             # 4 instead of 6 per output pair (2/3); F(4,3): 6 instead of 12 per output quad (1/2) -- so the algorithmic-equivalent
             # rate (what a direct kernel would need to match the time) is reported beside it and may exceed the peak.
             fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
+            if "bf16x3" in name:      # template argument TERMS: 3 bf16 MFMAs per product (split operands) or 1 (plain bf16 operands)
+                terms = 3 if name.rstrip(">+reduce").rstrip(">").endswith("3") else 1
+                fac, what = float(terms), ("direct, %d bf16 MFMA%s per product, fp32 accumulate" % (terms, "s" if terms > 1 else ""))
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach * fac, 2), "peak": peak_tflops, "unit": "TFLOP/s",
                     "frac": round(ach * fac / peak_tflops, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
@@ -288,18 +325,23 @@ def main():
             cpu = cpu_baseline(args.res_blocks, args.workload)
         parity = None
         if not args.no_alt and world == 1:
-            parity = full_size_parity(sr, args.res_blocks, dev)
+            parity = full_size_parity(sr, args.res_blocks, dev, args.workload)
+        step_name = {"gan": "G+D step", "g_only": "G-only warm-up step", "c4": "G-only warm-up step, configs[4]"}[args.workload]
+        img = "64->256 jet images" if channels == 1 else "3-channel 128->512 images"
+        dtype = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate)",
+                 "bf16": "bf16 (MFMA operands; fp32 accumulate, fp32 master weights and activations) -- stands in for configs[4]'s fp16: "
+                         "same MFMA rate on gfx950, no loss scaling needed"}[precision]
         out = {
-            "metric": "HR-pixels/s + ms/iter (G+D step), 64->256 jet images" if args.workload == "gan"
-                      else "HR-pixels/s + ms/iter (G-only warm-up step), 64->256 jet images",
+            "metric": f"HR-pixels/s + ms/iter ({step_name}), {img}",
             "value": value, "unit": "HR-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 MFMA operands, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: GeneratorRRDB(1,64,{args.res_blocks},num_upsample=2) 64x64->256x256, "
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GeneratorRRDB({channels},64,{args.res_blocks},num_upsample=2) "
+                                   f"{hr_px // FACTOR}x{hr_px // FACTOR}->{hr_px}x{hr_px}, "
                                    f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
-                                                           if args.workload == "gan" else ", L1 + Adam"),
+                                                           if wl["step"] == "gan" else ", L1 + Adam"),
                        "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
-                       "generator_train_gflop_per_image": 971.4,
+                       "generator_train_gflop_per_image": 971.4 if channels == 1 else 3887.6,
                        "inputs": "the same synthetic batch every step (resident in HBM); tools/soak.py with a fresh batch per "
                                  "iteration measures the same ms/iter, and the d_threshold gate stays open on it"},
             "roofline": roof, "cpu_baseline": cpu, "split_bf16_mode": alt, "full_size_parity": parity,

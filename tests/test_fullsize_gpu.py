@@ -152,3 +152,48 @@ def test_generator_with_f43_kernels_on_ragged_width_vs_oracle(srk):
     worst = max(((p.grad.cpu() - sdo[k].grad).abs().max() / sdo[k].grad.abs().max().clamp_min(1e-4)).item()
                 for k, p in gen.named_parameters() if p.grad is not None)
     assert worst < 2e-3, worst
+
+
+def test_full_depth_generator_gradients_vs_oracle(full_generator):
+    """F=64, R=23, 4x (BASELINE configs[1]/[2] architecture), one 64x64 jet image: forward + L1 backward through all 351
+    convolutions; weight gradients at the head, in the first, a middle and the last RRDB, and in the tail vs the CPU oracle
+    (models.py:9-135 + autograd).  ~10 s of CPU."""
+    gen, sd = full_generator
+    gen._engine.precision = "f32"
+    lr, hr = O.jet_images(1, 1, 256, 256, 77, 4)
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, lr, 23, 2, 0.2, training=True)
+    O.warmup_loss(yo, hr).backward()
+    gen.zero_grad()
+    y = gen(lr.cuda())
+    assert ((y.detach().cpu() - yo.detach()).abs().max() / yo.detach().abs().max()).item() < 2e-5
+    (y - hr.cuda()).abs().mean().backward()
+    named = dict(gen.named_parameters())
+    keys = ["conv1.weight", "conv1.bias", "res_blocks.0.dense_blocks.0.b1.0.weight", "res_blocks.11.dense_blocks.1.b5.0.weight",
+            "res_blocks.11.dense_blocks.1.b3.0.bias", "res_blocks.22.dense_blocks.2.b5.0.weight", "res_blocks.22.dense_blocks.0.b2.0.weight",
+            "conv2.weight", "upsampling.0.weight", "upsampling.3.weight", "conv3.0.weight", "conv3.2.weight", "conv3.2.bias"]
+    for k in keys:
+        ref = sdo[k].grad
+        err = ((named[k].grad.cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+        assert err < 2e-3, (k, err)
+
+
+def test_batch32_shaped_launch_set_gradients_vs_oracle(srk):
+    """N = 26 >= 25 images of 64x64 (the batch-32-shaped launch set: the engine picks the Winograd F(4,3) conv kernels at the
+    LR level, the batched Winograd weight-gradient kernel runs 13 pixel splits) on a 2-RRDB generator: forward and EVERY weight
+    and bias gradient through engine.backward vs the CPU oracle."""
+    gen = srk.GeneratorRRDB(1, filters=64, num_res_blocks=2, num_upsample=1, res_scale=0.1).cuda()
+    sd = O.default_init_generator(5, channels=1, filters=64, num_res_blocks=2, num_upsample=1)
+    gen.load_state_dict(sd)
+    Nb, Hb, Wb = 26, 64, 64
+    assert gen._engine._wino4_levels((Nb, Hb, Wb)) == (True, True)
+    lr, hr = O.jet_images(Nb, 1, 2 * Hb, 2 * Wb, 78, 2)
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, lr, 2, 1, 0.1, training=True)
+    O.warmup_loss(yo, hr).backward()
+    y = gen(lr.cuda())
+    assert ((y.detach().cpu() - yo.detach()).abs().max() / yo.detach().abs().max()).item() < 2e-5
+    (y - hr.cuda()).abs().mean().backward()
+    worst = max((((p.grad.cpu() - sdo[k].grad).abs().max() / sdo[k].grad.abs().max().clamp_min(1e-12)).item(), k)
+                for k, p in gen.named_parameters() if p.grad is not None)
+    assert worst[0] < 2e-3, worst
