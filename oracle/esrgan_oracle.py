@@ -131,11 +131,21 @@ def _out(x: Tensor, thres: float, pw: float, training: bool) -> Tensor:
     return F.hardshrink(F.relu(x), lambd=lambd)
 
 
+def upsample_kinds(num_upsample: int, use_transposed_conv: bool = False, fully_tconv_upsample: bool = False):
+    """models.py:69-90: per upsampling stage "shuffle" (conv F->4F, LeakyReLU, PixelShuffle(2)) or "tconv"
+    (ConvTranspose2d(F, F, 2, stride 2), LeakyReLU): odd stages with use_transposed_conv, every stage with fully_tconv_upsample
+    (use_transposed_conv takes precedence: it is tested first, models.py:70)."""
+    if use_transposed_conv:
+        return ["tconv" if u % 2 == 1 else "shuffle" for u in range(num_upsample)]
+    return ["tconv" if fully_tconv_upsample else "shuffle"] * num_upsample
+
+
 def generator_forward(sd, x: Tensor, num_res_blocks: int, num_upsample: int,
                       res_scale: float = 0.2, training: bool = True, thres: float = 0.0,
-                      num_final_layer_res: int = 0) -> Tuple[Tensor, Tensor]:
-    """GeneratorRRDB.forward, models.py:120-135 (default upsampling branch 84-90).
-    Returns (output, srs)."""
+                      num_final_layer_res: int = 0, use_transposed_conv: bool = False,
+                      fully_tconv_upsample: bool = False) -> Tuple[Tensor, Tensor]:
+    """GeneratorRRDB.forward, models.py:120-135 (upsampling branches 69-90; nn.Sequential indices: a "shuffle" stage takes
+    three slots, a "tconv" stage two).  Returns (output, srs)."""
     power = sd["power"]
     mult = sd["multiplier"]
     x = mult * (x ** power)
@@ -145,10 +155,15 @@ def generator_forward(sd, x: Tensor, num_res_blocks: int, num_upsample: int,
         out = rrdb(sd, f"res_blocks.{i}", out, res_scale)
     out2 = conv3x3(out, sd["conv2.weight"], sd["conv2.bias"])
     out = out1 + out2
-    for u in range(num_upsample):
-        out = conv3x3(out, sd[f"upsampling.{3*u}.weight"], sd[f"upsampling.{3*u}.bias"])
-        out = lrelu(out, G_SLOPE)
-        out = pixel_shuffle(out, 2)
+    idx = 0
+    for kind in upsample_kinds(num_upsample, use_transposed_conv, fully_tconv_upsample):
+        if kind == "shuffle":
+            out = conv3x3(out, sd[f"upsampling.{idx}.weight"], sd[f"upsampling.{idx}.bias"])
+            out = pixel_shuffle(lrelu(out, G_SLOPE), 2)
+            idx += 3
+        else:
+            out = lrelu(F.conv_transpose2d(out, sd[f"upsampling.{idx}.weight"], sd[f"upsampling.{idx}.bias"], stride=2), G_SLOPE)
+            idx += 2
     if num_final_layer_res > 0:
         o3 = out
         for i in range(num_final_layer_res):
@@ -164,7 +179,7 @@ def generator_forward(sd, x: Tensor, num_res_blocks: int, num_upsample: int,
 
 
 def generator_state_shapes(channels=1, filters=64, num_res_blocks=10, num_upsample=1,
-                           num_final_layer_res=0) -> Dict[str, Tuple[int, ...]]:
+                           num_final_layer_res=0, use_transposed_conv=False, fully_tconv_upsample=False) -> Dict[str, Tuple[int, ...]]:
     """state_dict key -> shape for GeneratorRRDB (models.py:58-106)."""
     F_ = filters
     sh = {"power": (1,), "multiplier": (1,),
@@ -180,9 +195,16 @@ def generator_state_shapes(channels=1, filters=64, num_res_blocks=10, num_upsamp
     add_rrdbs("res_blocks", num_res_blocks)
     sh["conv2.weight"] = (F_, F_, 3, 3)
     sh["conv2.bias"] = (F_,)
-    for u in range(num_upsample):
-        sh[f"upsampling.{3*u}.weight"] = (4 * F_, F_, 3, 3)
-        sh[f"upsampling.{3*u}.bias"] = (4 * F_,)
+    idx = 0
+    for kind in upsample_kinds(num_upsample, use_transposed_conv, fully_tconv_upsample):
+        if kind == "shuffle":
+            sh[f"upsampling.{idx}.weight"] = (4 * F_, F_, 3, 3)
+            sh[f"upsampling.{idx}.bias"] = (4 * F_,)
+            idx += 3
+        else:
+            sh[f"upsampling.{idx}.weight"] = (F_, F_, 2, 2)       # ConvTranspose2d: (in, out, kH, kW)
+            sh[f"upsampling.{idx}.bias"] = (F_,)
+            idx += 2
     add_rrdbs("res_blocks_final", num_final_layer_res)
     sh["conv3.0.weight"] = (F_, F_, 3, 3)
     sh["conv3.0.bias"] = (F_,)

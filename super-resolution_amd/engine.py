@@ -83,6 +83,14 @@ class GeneratorEngine:
         self._side = None            # second HIP stream: weight-gradient kernels overlap the data-gradient chain
         self.overlap_wgrad = os.environ.get("SRK_OVERLAP_WGRAD", "0") != "0"   # measured +1.2 % only; off keeps per-kernel timing clean
 
+    def __getstate__(self):
+        """Pickling / torch.save(module) / multiprocessing spawn: everything but the module reference and the flags is a cache
+        (packed weights, pack tables, graphs, streams) that is rebuilt on the first forward."""
+        keep = ("gen", "_sync", "_grad_scale", "precision", "use_graphs", "overlap_wgrad")
+        st = {k: self.__dict__[k] for k in keep}
+        st.update(_sig=None, _graphs={}, _side=None)
+        return st
+
     # ------------------------------------------------------------------ data-parallel gradient exchange
     def enable_grad_sync(self, enabled: bool = True):
         """Average weight gradients across ranks (RCCL all-reduce via torch.distributed) inside backward().
@@ -195,11 +203,7 @@ class GeneratorEngine:
                 return 0
             # F(4,3) works on 32 x 16 tiles, one 8-wave workgroup per CU: worth it when those tiles fill the chip and do not
             # pad the image more than the 16 x 16 tiles of the F(2,3) kernel would
-            h, w = gH * up, gW * up
-            wgs = gN * ((h + 31) // 32) * ((w + 15) // 16) * (M // 64)
-            if wino4 and wgs >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16:
-                return 5
-            return 3
+            return 5 if (wino4 and self._wino4_ok(geo, up, M // 64)) else 3
 
         def simple(name, conv, ps=False, need_bwd=True, up=1):
             co, ci = conv.weight.shape[:2]
@@ -262,14 +266,18 @@ class GeneratorEngine:
         for t in list(self.tab_f.values()) + list(self.tab_b.values()):
             t.finalize()
 
-    def _wino4_levels(self, geo):
-        """which resolution levels (1x, 2x, ... of the LR extent) run the F(4,3) kernel for a 64-output conv"""
+    @staticmethod
+    def _wino4_ok(geo, up, mtiles):
+        """THE rule for F(4,3) vs F(2,3): a conv at `up` x the LR extent with `mtiles` 64-channel output tiles runs the F(4,3)
+        kernel (32 x 16 pixel tiles, one 8-wave workgroup per CU) when those tiles fill the chip (>= 200 workgroups) and pad the
+        image no more than the 16-row tiles of the F(2,3) kernel would."""
         gN, gH, gW = geo
-        out = []
-        for u in range(self.gen.num_upsample + 1):
-            h, w = gH * 2 ** u, gW * 2 ** u
-            out.append(gN * ((h + 31) // 32) * ((w + 15) // 16) >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16)
-        return tuple(out)
+        h, w = gH * up, gW * up
+        return gN * ((h + 31) // 32) * ((w + 15) // 16) * mtiles >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16
+
+    def _wino4_levels(self, geo, mtiles=1):
+        """which resolution levels (1x, 2x, ... of the LR extent) run the F(4,3) kernel for a conv with `mtiles` output tiles"""
+        return tuple(self._wino4_ok(geo, 2 ** u, mtiles) for u in range(self.gen.num_upsample + 1))
 
     def _ensure_packed(self, need_bwd: bool, geo=None):
         """(Re)pack the weights.  The canonical OIHW Parameters stay the source of truth (optimizer steps,
@@ -279,8 +287,9 @@ class GeneratorEngine:
         dev = ps[0].device
         geo = geo or getattr(self, "_geo", (1, 16, 16))
         self._geo = geo
-        # the tables depend on the geometry only through the F(4,3)-vs-F(2,3) decision per resolution level
-        sig = (dev, self.precision, self._wino4_levels(geo), tuple(p.data_ptr() for p in ps))
+        # the tables depend on the geometry only through the F(4,3)-vs-F(2,3) decisions: per resolution level, for the 64-output
+        # convs (1 output tile) and the 4F PixelShuffle convs (4 tiles) -- the same rule fmt_of applies (_wino4_ok)
+        sig = (dev, self.precision, self._wino4_levels(geo, 1), self._wino4_levels(geo, 4), tuple(p.data_ptr() for p in ps))
         if sig != self._sig:
             self._build_tables(dev, geo)
             self._sig = sig

@@ -24,25 +24,42 @@ import torch
 
 from . import train as _train
 
-# values of the reference's options/default.json for the options this build implements
+# Every key of the reference's options/default.json with its value there (esrgan.py:30-133 declares one flag per key), plus
+# the parser-only flags of esrgan.py:117-131 and this build's two additions at the end.
 DEFAULTS = dict(
-    n_epochs=50, dataset_path="../data/tops_80.h5", dataset_type="synthetic", batch_size=8, factor=2, lr=0.0002, lr_g=0.0,
-    lr_d=0.0, l2decay=0.0, b1=0.9, b2=0.999, hr_height=80, hr_width=80, channels=1, scaling_power=1, residual_blocks=10,
+    n_epochs=50, dataset_path="../data/tops_80.h5", dataset_type="spjet", batch_size=8, factor=2, pre_factor=1, lr=0.0002, lr_g=0.0,
+    lr_d=0.0, l2decay=0.0, b1=0.9, b2=0.999, n_cpu=0, hr_height=80, hr_width=80, channels=1, scaling_power=1, sample_interval=500,
+    image_path="images", checkpoint_interval=500, validation_interval=1000, evaluation_interval=1000, residual_blocks=10,
     warmup_batches=500, pixel_multiplier=1, lambda_pix=0.2, lambda_hr=1, lambda_adv=0.01, lambda_lr=0.1, lambda_hist=0,
-    lambda_wasser=0, lambda_nnz=0, lambda_mask=0, lambda_pow=1, lambda_hit=0, learn_warmup=True, name="", root="",
-    model_path="saved_models", load_checkpoint=None, report_freq=10, discriminator="patch", relativistic=True, save=True,
-    save_info=None, checkpoint_interval=500, n_checkpoints=-1, n_batches=-1, d_threshold=0.001, d_channels=[16, 32, 32, 64],
-    E_thres=None, set_seed=-1, drop_rate=0, res_scale=0.1, lambda_reg=0.01, update_d=1, update_g=1, conditional=False,
-    wasserstein=-1, second_discr_reset_interval=0, uniform_init=False, use_transposed_conv=False,
-    fully_transposed_conv=False, num_final_res_blocks=0, synthetic_batches=100, hit_threshold=0.5, sigma=500, bins=10,
-    batchwise_hist=False,
+    lambda_wasser=0, lambda_nnz=0, lambda_mask=0, lambda_pow=1, lambda_hit=0, hit_threshold=0.5, batchwise_hist=False,
+    learn_warmup=True, sigma=500, bins=10, name="", root="", model_path="saved_models", validation_path=None, testset_path=None,
+    load_checkpoint=None, report_freq=10, discriminator="patch", relativistic=True, save=True, save_info=None, validate=None,
+    n_checkpoints=-1, n_batches=-1, n_validations=-1, n_evaluation=-1, plot_grad=False, smart_save=False, N=5000, wait=[],
+    d_threshold=0.001, sinkhorn_eps=0.1, d_channels=[16, 32, 32, 64], n_hardest=None, E_thres=None, set_seed=-1, deterministic=False,
+    eval_modes=["E_1", "E_2", "E_3", "E_4", "E_5", "E_10", "E_20", "E_30", "meanimg"], drop_rate=0, res_scale=0.1, lambda_reg=0.01,
+    emd_save=False, update_d=1, update_g=1, conditional=False, noise_factor=None, second_discr_reset_interval=0, uniform_init=False,
+    uniform_reset=False, save_late=-1,
+    # parser-only flags (esrgan.py:117-131)
+    use_transposed_conv=False, fully_transposed_conv=False, num_final_res_blocks=0, wasserstein=-1, set_zero_def=[], set_zero_pow=[],
+    nth_jet_eval_mode="hr", split_eval=False,
+    # this build: synthetic jet batches when no dataset file is at hand (--dataset_type synthetic)
+    synthetic_batches=100,
 )
+# Accepted and without effect here: they steer the reference's validation / evaluation / plotting scaffolding and its data
+# loader threads (outside the hot path), so launch scripts and json option files that carry them keep working.
+IGNORED = ("n_cpu", "sample_interval", "image_path", "validation_interval", "evaluation_interval", "validation_path", "testset_path",
+           "validate", "n_validations", "n_evaluation", "plot_grad", "N", "eval_modes", "emd_save", "deterministic", "sinkhorn_eps",
+           "nth_jet_eval_mode", "split_eval", "batchwise_hist")
+# Options whose non-default value asks for something this build does not implement: raise instead of training something else.
 UNSUPPORTED_POSITIVE = ("lambda_wasser", "second_discr_reset_interval")
-# the reference's loss_dict keys, in its order (esrgan.py:355-356)
+UNSUPPORTED_NONDEFAULT = ("smart_save", "wait", "set_zero_def", "set_zero_pow", "uniform_reset")
 # flags the reference declares with type=float although their default.json value is an integer literal (esrgan.py:58-120)
 FLOAT_FLAGS = {"lr", "lr_g", "lr_d", "l2decay", "b1", "b2", "scaling_power", "pixel_multiplier", "lambda_pix", "lambda_hr", "lambda_adv",
                "lambda_lr", "lambda_hist", "lambda_wasser", "lambda_nnz", "lambda_mask", "lambda_pow", "lambda_hit", "d_threshold",
-               "drop_rate", "res_scale", "lambda_reg", "wasserstein", "sigma", "hit_threshold"}
+               "drop_rate", "res_scale", "lambda_reg", "wasserstein", "sigma", "hit_threshold", "E_thres", "noise_factor", "sinkhorn_eps"}
+INT_NONE_FLAGS = {"n_hardest"}
+STR_LIST_FLAGS = {"wait", "eval_modes", "set_zero_def", "set_zero_pow"}
+# the reference's loss_dict keys, in its order (esrgan.py:355-356)
 LOSS_KEYS = ['d_loss_def', 'd_loss_pow', 'g_loss', 'def_loss', 'pow_loss', 'adv_loss', 'adv_loss_pow', 'pixel_loss',
              'pixel_loss_pow', 'lr_loss', 'lr_loss_pow', 'hist_loss', 'hist_loss_pow', 'nnz_loss', 'nnz_loss_pow', 'mask_loss',
              'mask_loss_pow', 'wasser_loss', 'wasser_loss_pow', 'hit_loss', 'hit_loss_pow', 'wasser_dist', 'wasser_dist_pow']
@@ -53,36 +70,59 @@ def _str2bool(v):
 
 
 def get_parser(argv=None):
-    """argparse Namespace with the reference's flag names (esrgan.py:30-149); ``--default file.json`` overlays a json of
-    options, explicit command-line flags win (esrgan.py:135-147)."""
+    """argparse Namespace with the reference's flag names (esrgan.py:30-133); ``--default file.json`` overlays a json of
+    options (or an info.json, whose options sit under "argument"), explicit command-line flags win (esrgan.py:135-147)."""
     ap = argparse.ArgumentParser(description="ESRGAN training on MI355X (super-resolution_amd)")
     for k, v in DEFAULTS.items():
-        if isinstance(v, bool):
-            ap.add_argument("--" + k, type=_str2bool, default=v)
+        flag = "-N" if k == "N" else "--" + k          # esrgan.py:86: "-N"
+        if k in STR_LIST_FLAGS:
+            ap.add_argument(flag, type=str, nargs="+", default=v)
+        elif k in INT_NONE_FLAGS:
+            ap.add_argument(flag, type=int, default=v)
+        elif isinstance(v, bool) or k in ("save_info", "validate"):
+            ap.add_argument(flag, type=_str2bool, default=v)
         elif isinstance(v, list):
-            ap.add_argument("--" + k, type=int, nargs="+", default=v)
+            ap.add_argument(flag, type=int, nargs="+", default=v)
         elif v is None:
-            ap.add_argument("--" + k, default=None, type=(float if k == "E_thres" else str))
+            ap.add_argument(flag, default=None, type=(float if k in FLOAT_FLAGS else str))
         else:
-            ap.add_argument("--" + k, type=(float if k in FLOAT_FLAGS else type(v)), default=v)
+            ap.add_argument(flag, type=(float if k in FLOAT_FLAGS else type(v)), default=v)
     ap.add_argument("--default", type=str, default=None, help="json file with option overrides")
     opt = ap.parse_args(argv)
     if opt.default:
         with open(opt.default) as f:
             over = json.load(f)
+        if "argument" in over:                          # an info.json was given (esrgan.py:139-140)
+            over = over["argument"]
         for k, v in over.items():
-            if k in DEFAULTS and getattr(opt, k) == DEFAULTS[k]:      # non-default CLI values win
+            if k not in DEFAULTS:
+                setattr(opt, k, v)                      # keys of other tools (hyper_search's n_histograms, ...) ride along
+            elif getattr(opt, k) == DEFAULTS[k]:        # non-default CLI values win
                 setattr(opt, k, v)
     return opt
 
 
 def options(**kw):
-    """Programmatic equivalent of get_parser(): defaults + overrides (hyper-search style callers)."""
+    """Programmatic equivalent of get_parser(): defaults + overrides (hyper-search style callers).  Unknown keys are kept as
+    attributes (hyper_search.py adds bookkeeping keys of its own to the namedtuple it passes to train())."""
     d = dict(DEFAULTS)
-    unknown = set(kw) - set(d)
-    if unknown:
-        raise TypeError(f"unknown option(s): {sorted(unknown)}")
     d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def _opt_dict(opt):
+    """esrgan.py:164-167: ``opt`` is an argparse Namespace or, from hyper_search.py:104,159 and the --default path, a namedtuple."""
+    try:
+        return dict(opt._asdict())
+    except AttributeError:
+        return dict(vars(opt))
+
+
+def _complete(opt):
+    """Namespace carrying every option this module reads: the caller's values over DEFAULTS (a namedtuple built from a json of
+    a few options, as constant_args.json + hyper_search.py produce, lacks the rest)."""
+    d = dict(DEFAULTS)
+    d.update(_opt_dict(opt))
     return SimpleNamespace(**d)
 
 
@@ -105,10 +145,11 @@ def _check_supported(opt):
     for k in UNSUPPORTED_POSITIVE:
         if getattr(opt, k, 0) and getattr(opt, k) > 0:
             raise NotImplementedError(f"option {k} > 0 is outside the hot path implemented by this build (SURVEY.md 2.1)")
+    for k in UNSUPPORTED_NONDEFAULT:
+        if getattr(opt, k, DEFAULTS[k]) != DEFAULTS[k]:
+            raise NotImplementedError(f"option {k}={getattr(opt, k)!r} is outside the hot path implemented by this build (SURVEY.md 2.1)")
     if opt.discriminator not in ("patch", "standard") or opt.wasserstein > 0:
         raise NotImplementedError("only the patch (Markovian), standard and conditional discriminators with the relativistic loss are implemented")
-    if opt.use_transposed_conv or opt.fully_transposed_conv:
-        raise NotImplementedError("transposed-conv upsampling branches are not implemented")
 
 
 def _set_binedges(st, opt, nnz, info):
@@ -139,6 +180,8 @@ def _set_binedges(st, opt, nnz, info):
 def train(opt, **kwargs):
     """Runs the training loop; returns the ``info`` dict that is also written to ``<model_path>/<name_>info.json``.
     kwargs: ``gpu`` (device index, esrgan.py:156), ``dataset`` (a torch Dataset yielding {"lr","hr"}; default synthetic)."""
+    given = _opt_dict(opt)
+    opt = _complete(opt)
     _check_supported(opt)
     if opt.lambda_hist > 0:
         assert opt.warmup_batches > 0, "if distribution learning is enabled, warmup_batches needs to be greater than 0."   # esrgan.py:159-160
@@ -160,7 +203,7 @@ def train(opt, **kwargs):
     info_path = os.path.join(out_dir, model_name + "info.json")
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
-    info = {"epochs": 0, "argument": dict(vars(opt))}
+    info = {"epochs": 0, "argument": given}
     if opt.set_seed > 0:
         torch.manual_seed(opt.set_seed)
         np.random.seed(opt.set_seed)
@@ -176,7 +219,8 @@ def train(opt, **kwargs):
                         scaling_power=opt.scaling_power, multiplier=opt.pixel_multiplier, hr_shape=(opt.hr_height, opt.hr_width),
                         num_final_layer_res=opt.num_final_res_blocks, uniform_init=opt.uniform_init, lambda_nnz=opt.lambda_nnz,
                         lambda_mask=opt.lambda_mask, lambda_hit=opt.lambda_hit, lambda_hist=opt.lambda_hist,
-                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional, drop_rate=opt.drop_rate, discriminator=opt.discriminator, relativistic=opt.relativistic)
+                        hit_threshold=opt.hit_threshold, sigma=opt.sigma, conditional=opt.conditional, drop_rate=opt.drop_rate, discriminator=opt.discriminator, relativistic=opt.relativistic,
+                        use_transposed_conv=opt.use_transposed_conv, fully_tconv_upsample=opt.fully_transposed_conv)
     if opt.E_thres:
         st.generator.thres = opt.E_thres
     load_chk = bool(opt.load_checkpoint)
@@ -198,8 +242,8 @@ def train(opt, **kwargs):
     if dataset is None:
         if opt.dataset_type in ("jet", "spjet"):   # datasets.py:316-329, from a .npy file of the dataframe's rows
             from . import datasets as _ds
-            dataset = _ds.get_dataset(opt.dataset_type, opt.dataset_path, opt.hr_height, opt.hr_width, opt.factor,
-                                      threshold=opt.E_thres)
+            dataset = _ds.get_dataset(opt.dataset_type, opt.dataset_path, opt.hr_height, opt.hr_width, opt.factor, pre=opt.pre_factor,
+                                      threshold=opt.E_thres, N=opt.n_hardest, noise_factor=opt.noise_factor)
         elif opt.dataset_type != "synthetic":
             raise NotImplementedError("the HDF5/text event datasets (datasets.py) are outside this build; pass dataset=..., use "
                                       "--dataset_type synthetic, or jet/spjet with a .npy row file")
@@ -285,8 +329,18 @@ def train(opt, **kwargs):
                           "pixel pow: %f, lr pixel: %f, lr pixel pow: %f, hist: %f, hist pow: %f, nnz: %f, nnz pow: %f, mask: %f, "
                           "mask pow: %f, wasser: %f, wasser pow: %f, hit: %f, hit pow: %f, wasserdist: %f, wasserdist pow: %f]"
                           % ((batches_done,) + tuple(vals[k] for k in LOSS_KEYS)))
-            if opt.n_checkpoints == -1 and opt.checkpoint_interval > 0 and batches_done % opt.checkpoint_interval == 0 and batches_done > 0:
+            # esrgan.py:280-283,780-783: every checkpoint_interval batches, or n_checkpoints times over the run when that is given
+            if opt.n_checkpoints != -1:
+                every = max(int(total_batches // opt.n_checkpoints), 1) if total_batches != math.inf else 0
+            else:
+                every = opt.checkpoint_interval
+            if every > 0 and (batches_done + 1) % every == 0:
                 save_weights(epoch)
+            if opt.save_late > 0 and (batches_done - batches_trained + 1) == opt.save_late:      # esrgan.py:800-804
+                if opt.save and rank == 0:
+                    torch.save(st.generator.state_dict(), os.path.join(out_dir, "%sgenerator_%s_ep%i.pth" % (model_name, "late_save", epoch)))
+                    for k, D in st.discriminators.items():
+                        torch.save(D.state_dict(), os.path.join(out_dir, "%sdiscriminator%s_%s_ep%i.pth" % (model_name, ["", "_pow"][k], "late_save", epoch)))
             if batches_done + 1 >= total_batches:
                 break
         info["epochs"] = epoch + 1

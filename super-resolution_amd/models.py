@@ -89,8 +89,6 @@ class GeneratorRRDB(nn.Module):
     def __init__(self, channels=1, filters=64, num_res_blocks=10, num_upsample=1, power=1, multiplier=1, drop_rate=0,
                  res_scale=0.2, use_transposed_conv=False, fully_tconv_upsample=False, num_final_layer_res=0, uniform_init=False):
         super().__init__()
-        if use_transposed_conv or fully_tconv_upsample:
-            raise NotImplementedError("the ConvTranspose2d upsampling branches (models.py:70-83) are outside the hot path of this build")
         if filters % 8 != 0:
             raise NotImplementedError("filters must be a multiple of 8 (8-channel K chunks of the MFMA kernels)")
         self.channels, self.filters, self.num_upsample = channels, filters, num_upsample
@@ -100,11 +98,22 @@ class GeneratorRRDB(nn.Module):
         self.res_blocks = nn.Sequential(*[ResidualInResidualDenseBlock(filters, res_scale=res_scale, drop_rate=drop_rate)
                                           for _ in range(num_res_blocks)])
         self.conv2 = Conv3x3(filters, filters, kernel_size=3, stride=1, padding=1)
+        # Upsampling stages (models.py:69-90).  Default: conv F->4F + LeakyReLU + PixelShuffle(2), fused into the HIP engine.
+        # The two non-default variants put a ConvTranspose2d(F, F, 2, stride 2) + LeakyReLU at every odd stage
+        # (use_transposed_conv) or at every stage (fully_tconv_upsample): those layers are plain PyTorch modules (SURVEY 8b:
+        # non-default branches may stay on PyTorch ops) and the generator then runs module by module, every 3x3 conv still
+        # on the HIP kernels, so checkpoints trained with these flags load and run.
+        kinds = ["tconv" if (fully_tconv_upsample and not use_transposed_conv) or (use_transposed_conv and u % 2 == 1) else "shuffle"
+                 for u in range(num_upsample)]
         upsample_layers = []
-        for _ in range(num_upsample):
-            upsample_layers += [Conv3x3(filters, filters * 4, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
-                                nn.PixelShuffle(upscale_factor=2)]
+        for kind in kinds:
+            if kind == "shuffle":
+                upsample_layers += [Conv3x3(filters, filters * 4, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                                    nn.PixelShuffle(upscale_factor=2)]
+            else:
+                upsample_layers += [nn.ConvTranspose2d(filters, filters, kernel_size=2, stride=2, padding=0), nn.LeakyReLU()]
         self.upsampling = nn.Sequential(*upsample_layers)
+        self.modulewise = drop_rate > 0 or "tconv" in kinds      # these run _forward_modulewise instead of the fused engine
         if num_final_layer_res > 0:
             self.res_blocks_final = nn.Sequential(*[ResidualInResidualDenseBlock(filters, res_scale=res_scale, drop_rate=drop_rate)
                                                     for _ in range(num_final_layer_res)])
@@ -114,7 +123,7 @@ class GeneratorRRDB(nn.Module):
         self.power = nn.Parameter(torch.Tensor([power]), False)
         self.multiplier = nn.Parameter(torch.Tensor([multiplier]), False)
         self._scalars = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_scalars", None))
+        self.register_load_state_dict_post_hook(_drop_scalar_cache)     # a module-level function: the module stays picklable
         self._engine = GeneratorEngine(self)
         if uniform_init:
             self.init_conv2d()
@@ -127,12 +136,26 @@ class GeneratorRRDB(nn.Module):
                 nn.init.constant_(c.bias, 0.)
 
     def _power_multiplier(self):
-        """Host copies of the two frozen scalars, refreshed only when the Parameters change (the reference
-        syncs on them every forward, models.py:116,133)."""
+        """Host copies of the two frozen scalars (the reference syncs on them every forward, models.py:116,133).  In training
+        mode they are cached -- two device->host syncs per forward would drain the launch queue of the hot loop -- and re-read
+        when the Parameters were replaced or written through autograd-visible ops, on load_state_dict / .to() / .train() /
+        .eval(), and on refresh_scalars(); in eval mode they are read on every forward.  (A bare ``gen.power.data.fill_(p)``
+        bumps no version counter: follow it with gen.train(), gen.eval() or gen.refresh_scalars().)"""
         key = (self.power.data_ptr(), self.power._version, self.multiplier.data_ptr(), self.multiplier._version)
-        if self._scalars is None or self._scalars[0] != key:
+        if self._scalars is None or self._scalars[0] != key or not self.training:
             self._scalars = (key, float(self.power.item()), float(self.multiplier.item()))
         return self._scalars[1], self._scalars[2]
+
+    def refresh_scalars(self):
+        self._scalars = None
+
+    def train(self, mode=True):
+        self._scalars = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._scalars = None
+        return super()._apply(fn, *args, **kwargs)
 
     def out(self, x, pow=1.0):
         lambd = float(self.thres) ** float(pow)
@@ -141,7 +164,8 @@ class GeneratorRRDB(nn.Module):
         return F.hardshrink(F.relu(x), lambd=lambd)
 
     def _forward_modulewise(self, x):
-        """models.py:123-132 module by module (every Conv3x3 still runs the HIP kernel); used for drop_rate > 0 only."""
+        """models.py:123-132 module by module (every Conv3x3 still runs the HIP kernel); used for drop_rate > 0 and for the
+        ConvTranspose2d upsampling variants."""
         if not x.is_cuda:
             raise RuntimeError("super-resolution_amd: the generator hot path only runs on a ROCm GPU tensor (no CPU fallback)")
         out1 = self.conv1(x)
@@ -158,8 +182,8 @@ class GeneratorRRDB(nn.Module):
         power, mult = self._power_multiplier()
         if power != 1.0 or mult != 1.0:
             x = self.multiplier * (x ** self.power)
-        if self.drop_rate > 0:
-            out = self._forward_modulewise(x)        # Dropout2d in every dense block: the fused engine has no slot for it
+        if self.modulewise:
+            out = self._forward_modulewise(x)        # Dropout2d in the dense blocks / ConvTranspose2d stages: no slot in the fused engine
         else:
             out = generator_raw(self._engine, x)
         if mult != 1.0:
@@ -168,6 +192,10 @@ class GeneratorRRDB(nn.Module):
         if power != 1.0:
             out = F.relu(out) ** (1 / self.power)
         return self.out(out)
+
+
+def _drop_scalar_cache(module, incompatible_keys):
+    module._scalars = None
 
 
 def discriminator_block(in_filters, out_filters, stride=(1, 2)):

@@ -45,7 +45,8 @@ class Stepper:
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
                  lambda_hr=1.0, lambda_adv=0.01, lambda_lr=0.1, lambda_reg=0.01, d_threshold=0.001, scaling_power=1.0,
                  exact_dp=True, hr_shape=None, lr_g=0.0, lr_d=0.0, weight_decay=0.0, multiplier=1.0, num_final_layer_res=0,
-                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0, discriminator="patch", relativistic=True):
+                 uniform_init=False, lambda_nnz=0.0, lambda_mask=0.0, lambda_hit=0.0, lambda_hist=0.0, hit_threshold=0.5, sigma=500.0, conditional=False, drop_rate=0.0, discriminator="patch", relativistic=True,
+                 use_transposed_conv=False, fully_tconv_upsample=False):
         self.workload = workload
         self.drop_rate = drop_rate
         self.relativistic = relativistic
@@ -66,7 +67,8 @@ class Stepper:
         self.generator = models.GeneratorRRDB(channels, filters=filters, num_res_blocks=res_blocks,
                                               num_upsample=int(math.log2(factor)), res_scale=res_scale,
                                               power=scaling_power, multiplier=multiplier, num_final_layer_res=num_final_layer_res,
-                                              uniform_init=uniform_init, drop_rate=drop_rate).to(device)
+                                              uniform_init=uniform_init, drop_rate=drop_rate, use_transposed_conv=use_transposed_conv,
+                                              fully_tconv_upsample=fully_tconv_upsample).to(device)
         # esrgan.py:299,305: Adam(lr_g or lr), Adam(lr_d or lr); fused=True is the same arithmetic in one launch
         self.optimizer_G = torch.optim.Adam([p for p in self.generator.parameters() if p.requires_grad],
                                             lr=lr_g if lr_g > 0 else lr, betas=betas, weight_decay=weight_decay, fused=True)
@@ -87,8 +89,8 @@ class Stepper:
                         D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     self.discriminators[k] = D
                     self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas, fused=True)
-        if distributed and not drop_rate > 0:
-            self.generator._engine.enable_grad_sync()      # (drop_rate > 0 runs module-wise: gradients go through _sync_grads)
+        if distributed and not self.generator.modulewise:
+            self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         self.last = {}
 
     # ------------------------------------------------------------------ helpers
@@ -149,7 +151,7 @@ class Stepper:
         gen_hr = self.generator(imgs_lr)
         loss_pixel = self.criterion_pixel(gen_hr, imgs_hr)
         loss_pixel.backward()
-        if self.drop_rate > 0:
+        if self.generator.modulewise:
             self._sync_grads(self.generator)
         self.optimizer_G.step()
         self.last = {"g_loss": loss_pixel.detach()}
@@ -254,7 +256,7 @@ class Stepper:
         if update_g:
             loss_G, generated, ground_truth, parts = self.g_phase_loss(imgs_lr, imgs_hr)
             loss_G.backward()
-            if self.drop_rate > 0:
+            if self.generator.modulewise:
                 self._sync_grads(self.generator)
             self.optimizer_G.step()
             # drop the 702 gradient views now, while the GPU is busy with the D phase: at the top of the next iteration this

@@ -94,8 +94,6 @@ def test_discriminator_surface(srk, golden_dir):
 
 def test_unsupported_branches_raise(srk):
     with pytest.raises(NotImplementedError):
-        srk.GeneratorRRDB(use_transposed_conv=True)
-    with pytest.raises(NotImplementedError):
         srk.Conv3x3(3, 3, 5, 1, 2)
     # drop_rate > 0 is supported (module-wise branch): same state_dict keys, Dropout2d modules hold no parameters
     g = srk.GeneratorRRDB(1, 16, 1, drop_rate=0.1)
@@ -257,3 +255,58 @@ def test_exact_dp_statistic_exchange_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_reference_option_sets_go_through_the_parser(golden_dir, tmp_path):
+    """The reference's own option data (options/default.json, options/constant_args.json; tools/make_golden_options.py) through
+    get_parser / options / the namedtuple path of hyper_search.py:104: every key is declared with the reference's default, json
+    overlays work (also from an info.json), unknown bookkeeping keys ride along, and a namedtuple is accepted by train()'s
+    option handling (esrgan.py:164-167)."""
+    import importlib
+    import json
+    from collections import namedtuple
+    es = importlib.import_module("super-resolution_amd.esrgan")
+    ref = json.load(open(os.path.join(golden_dir, "ref_options.json")))
+    dflt, const = ref["default"], ref["constant_args"]
+    opt = es.get_parser([])
+    for k, v in dflt.items():
+        if k == "default":
+            continue
+        assert hasattr(opt, k), k
+        assert getattr(opt, k) == v, (k, getattr(opt, k), v)
+    # constant_args.json as --default overlay; an explicit flag wins; an info.json ("argument": {...}) works too
+    f1 = tmp_path / "const.json"; f1.write_text(json.dumps(const))
+    o1 = es.get_parser(["--default", str(f1), "--batch_size", "16"])
+    assert o1.n_epochs == 20 and o1.sample_interval == -1 and o1.warmup_batches == 0 and o1.batch_size == 16 and o1.n_cpu == 0
+    f2 = tmp_path / "info.json"; f2.write_text(json.dumps({"argument": {**const, "n_histograms": 1}, "epochs": 3}))
+    o2 = es.get_parser(["--default", str(f2)])
+    assert o2.residual_blocks == 10 and o2.n_histograms == 1
+    # the reference's own flags that this build ignores or rejects parse with the reference's syntax
+    o3 = es.get_parser(["-N", "100", "--wait", "hist", "2e4", "--set_zero_def", "hr", "lr", "--eval_modes", "E_1", "meanimg", "--n_hardest", "5",
+                        "--noise_factor", "0.1", "--E_thres", "0.5", "--save_info", "false"])
+    assert o3.N == 100 and o3.wait == ["hist", "2e4"] and o3.set_zero_def == ["hr", "lr"] and o3.n_hardest == 5 and o3.noise_factor == 0.1
+    assert o3.save_info is False
+    with pytest.raises(NotImplementedError):
+        es._check_supported(es._complete(o3))
+    # hyper_search.py:96-104: a namedtuple of a FEW options plus its own bookkeeping keys
+    args = {**const, "name": "hs0", "n_batches": 10, "n_validations": 2, "n_histograms": -1, "metric_results": []}
+    nt = namedtuple("arguments", args.keys())(*args.values())
+    full = es._complete(nt)
+    assert es._opt_dict(nt)["metric_results"] == [] and full.lambda_reg == dflt["lambda_reg"] and full.n_batches == 10 and full.batch_size == 4
+    es._check_supported(full)
+    assert es.options(foo=1).foo == 1
+
+
+def test_transposed_conv_variants_keep_the_reference_state_dict(srk, golden_dir):
+    """models.py:69-83: --use_transposed_conv / --fully_transposed_conv generators have the reference's state_dict keys and
+    shapes (G16 key lists written from the imported reference), so its checkpoints load; they survive pickling like any module."""
+    import pickle
+    lines = dict(l.split(": ", 1) for l in open(os.path.join(golden_dir, "G16_state_keys.txt")).read().strip().split("\n"))
+    for tag, kw in (("tc", dict(use_transposed_conv=True)), ("full", dict(fully_tconv_upsample=True))):
+        g = srk.GeneratorRRDB(1, 16, 1, num_upsample=2, res_scale=0.1, **kw)
+        assert list(g.state_dict().keys()) == lines[tag].split() and g.modulewise
+        shapes = O.generator_state_shapes(1, 16, 1, 2, **kw)
+        assert {k: tuple(v.shape) for k, v in g.state_dict().items()} == shapes
+        g2 = pickle.loads(pickle.dumps(g))
+        assert list(g2.state_dict().keys()) == lines[tag].split() and g2._engine.gen is g2
+    assert not srk.GeneratorRRDB(1, 16, 1).modulewise

@@ -485,3 +485,20 @@ def test_plain_bf16_mixed_precision_mode(srk, golden_dir):
     gen.zero_grad()
     y2 = gen(x)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("tag,kw", [("tc", dict(use_transposed_conv=True)), ("full", dict(fully_tconv_upsample=True))])
+def test_transposed_conv_generators_golden(srk, golden_dir, tag, kw):
+    """G16 (from the imported reference): the ConvTranspose2d upsampling variants (models.py:69-83) -- 3x3 convs on the HIP
+    kernels, the transposed convs on PyTorch -- forward, input gradient and weight gradients."""
+    d = np.load(os.path.join(golden_dir, "G16_tconv_generators.npz"))
+    gen = srk.GeneratorRRDB(1, 16, 1, num_upsample=2, res_scale=0.1, **kw).cuda()
+    _load_closed_form(gen)
+    x = torch.from_numpy(d[f"{tag}.lr"]).cuda().requires_grad_(True)
+    y = gen(x)
+    assert rel(y.detach().cpu(), torch.from_numpy(d[f"{tag}.y"])) < OUT_TOL
+    (y - torch.from_numpy(d[f"{tag}.tgt"]).cuda()).abs().mean().backward()
+    assert rel(x.grad.cpu(), torch.from_numpy(d[f"{tag}.dx"])) < GRAD_TOL
+    named = dict(gen.named_parameters())
+    for k in [k[len(tag) + 6:] for k in d.files if k.startswith(tag + ".grad.")]:
+        assert rel(named[k].grad.cpu(), torch.from_numpy(d[f"{tag}.grad.{k}"])) < GRAD_TOL, k

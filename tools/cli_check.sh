@@ -5,7 +5,7 @@ set -e
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/cli
 rm -rf $O; mkdir -p $O
-COMMON="--residual_blocks 2 --factor 2 --hr_height 32 --hr_width 32 --batch_size 4 --n_batches 6 --warmup_batches 2 --report_freq 1 --synthetic_batches 4 --root $O"
+COMMON="--residual_blocks 2 --factor 2 --hr_height 32 --hr_width 32 --batch_size 4 --n_batches 6 --warmup_batches 2 --report_freq 1 --synthetic_batches 4 --dataset_type synthetic --root $O"
 echo "== conditional"; python tools/train.py $COMMON --name cond --conditional true --d_channels 8 16 16 32 2>&1 | tail -1 | cut -c1-200
 echo "== heads + hist"; python tools/train.py $COMMON --name heads --lambda_hist 0.05 --bins 4 --sigma 5 --lambda_hit 2.5 --lambda_mask 0.5 --lambda_nnz 1e-6 2>&1 | tail -1 | cut -c1-200
 echo "== resume"; python tools/train.py $COMMON --name heads --load_checkpoint $O/saved_models/heads_generator_2.pth --lambda_hist 0.05 --bins 4 --sigma 5 2>&1 | tail -1 | cut -c1-200
@@ -15,7 +15,7 @@ echo "== update_g 2, d_threshold high"; python tools/train.py $COMMON --name ug 
 echo "== standard discriminator"; python tools/train.py $COMMON --name std --discriminator standard --d_channels 8 16 2>&1 | tail -1 | cut -c1-200
 echo "== non-relativistic"; python tools/train.py $COMMON --name nr --relativistic false 2>&1 | tail -1 | cut -c1-200
 echo "== drop_rate"; python tools/train.py $COMMON --name dr --drop_rate 0.2 2>&1 | tail -1 | cut -c1-200
-echo "== 3 channels, factor 4"; python tools/train.py --residual_blocks 1 --factor 4 --hr_height 32 --hr_width 48 --channels 3 --batch_size 2 --n_batches 4 --warmup_batches 1 --report_freq 1 --synthetic_batches 3 --root $O --name c3 2>&1 | tail -1 | cut -c1-200
+echo "== 3 channels, factor 4"; python tools/train.py --residual_blocks 1 --factor 4 --hr_height 32 --hr_width 48 --channels 3 --batch_size 2 --n_batches 4 --warmup_batches 1 --report_freq 1 --synthetic_batches 3 --dataset_type synthetic --root $O --name c3 2>&1 | tail -1 | cut -c1-200
 echo "== sparse jets from a .npy row table"
 python - <<'PY'
 import numpy as np
