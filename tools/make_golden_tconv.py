@@ -40,7 +40,7 @@ for tag, kw, U in (("tc", dict(use_transposed_conv=True), 2), ("full", dict(full
         assert (sdo[k].grad - ref_g).abs().max().item() <= 1e-6 * max(1.0, ref_g.abs().max().item()), (tag, k)
         out[f"{tag}.grad.{k}"] = ref_g.numpy()
     out[f"{tag}.lr"], out[f"{tag}.y"], out[f"{tag}.tgt"], out[f"{tag}.dx"] = lr.numpy(), y.detach().numpy(), tgt.numpy(), x.grad.numpy()
-    keys_txt.append(tag + ": " + " ".join(sd.keys()))
+    keys_txt.append(tag + ": " + " ".join(g.state_dict().keys()))
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "G16_tconv_generators.npz"), **out)
 open(os.path.join(ROOT, "tests", "golden", "G16_state_keys.txt"), "w").write("\n".join(keys_txt) + "\n")
 print("G16 written; oracle == reference for both variants")
