@@ -92,29 +92,36 @@ __global__ void permute_bias_kernel(const float* __restrict__ b, float* __restri
 }
 
 // ---------------------------------------------------------------- pixel shuffle (standalone)
-// x [N,H,W,4C] (channel = 4c + 2i + j)  ->  y [N,2H,2W,C]; one thread per output float4
+// x [N,H,W,4C] (channel = 4c + 2i + j)  ->  y [N,2H,2W,C]  (models.py:89; index map pinned bit-exact by G1).
+// One thread per (input pixel, c): the four values of a 2x2 output patch are ONE aligned float4 of x (channels 4c .. 4c+3);
+// consecutive lanes take consecutive c, so the read is a fully coalesced 16 B per lane and each of the four scatter stores
+// writes 4 B per lane into one contiguous run of an output pixel (256 B per wave at C = 64).  The backward is the mirror:
+// four gathered dwords, one 16-byte store.
 __global__ void pixel_shuffle_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
-  const long total = (long)N * 2 * H * 2 * W * C;
+  const long total = (long)N * H * W * C;
   for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
     long t = gid;
     const int c = (int)(t % C); t /= C;
-    const int ow = (int)(t % (2 * W)); t /= (2 * W);
-    const int oh = (int)(t % (2 * H)); t /= (2 * H);
-    const int n = (int)t;
-    const int h = oh >> 1, i = oh & 1, w = ow >> 1, j = ow & 1;
-    y[gid] = x[(((long)n * H + h) * W + w) * (4 * C) + 4 * c + 2 * i + j];
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const long n = t;
+    const float4 v = *reinterpret_cast<const float4*>(x + gid * 4);
+    float* o = y + (((n * 2 * H + 2 * h) * (2 * W)) + 2 * w) * C + c;
+    const long row = (long)2 * W * C;
+    o[0] = v.x; o[C] = v.y; o[row] = v.z; o[row + C] = v.w;
   }
 }
 __global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
-  const long total = (long)N * H * W * 4 * C;
+  const long total = (long)N * H * W * C;
   for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
     long t = gid;
-    const int ch = (int)(t % (4 * C)); t /= (4 * C);
+    const int c = (int)(t % C); t /= C;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); t /= H;
-    const int n = (int)t;
-    const int c = ch >> 2, i = (ch >> 1) & 1, j = ch & 1;
-    dx[gid] = dy[(((long)n * 2 * H + 2 * h + i) * (2 * W) + 2 * w + j) * C + c];
+    const long n = t;
+    const float* o = dy + (((n * 2 * H + 2 * h) * (2 * W)) + 2 * w) * C + c;
+    const long row = (long)2 * W * C;
+    *reinterpret_cast<float4*>(dx + gid * 4) = make_float4(o[0], o[C], o[row], o[row + C]);
   }
 }
 
@@ -224,14 +231,16 @@ extern "C" int srk_pack_weights_bf16x3(const srk_pack_entry* dev, int n, int64_t
 
 extern "C" int srk_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SRK_ERR_BAD_ARG;
-  const long total = (long)N * H * W * 4 * C;
+  if (((uintptr_t)x) & 15) return SRK_ERR_ALIGNMENT;
+  const long total = (long)N * H * W * C;
   hipLaunchKernelGGL(pixel_shuffle_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
 extern "C" int srk_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SRK_ERR_BAD_ARG;
-  const long total = (long)N * H * W * 4 * C;
+  if (((uintptr_t)dx) & 15) return SRK_ERR_ALIGNMENT;
+  const long total = (long)N * H * W * C;
   hipLaunchKernelGGL(pixel_shuffle_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C);
   SRK_CHECK_LAUNCH();
   return SRK_OK;

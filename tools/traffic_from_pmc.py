@@ -24,7 +24,7 @@ def load(d, counter):
 
 
 def short(name):
-    m = re.search(r"(conv3x3_f32_wino4_kernel<[^>]*>|wgrad_f32_wino_kernel<[^>]*>|conv3x3_f32_wino_kernel<[^>]*>|conv3x3_f32_lw_kernel<[^>]*>|conv3x3_f32_kernel<[^>]*>|wgrad_prereduce_kernel|wgrad_c1_kernel<[^>]*>|wgrad_f32_kernel<[^>]*>|wgrad_reduce_kernel|pack_kernel)", name)
+    m = re.search(r"((?:conv3x3|wgrad)_[a-z0-9_]+_kernel(?:<[^>]*>)?|pack_kernel)", name)
     return m.group(1) if m else None
 
 
