@@ -218,10 +218,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner on STDOUT when its communicator comes up (measured: 5 lines in front of the JSON line of a
+        # 1-rank rehearsal); route C-level stdout to stderr while the group and its first collective initialise
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            warm = torch.ones(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     wl = WORKLOADS[args.workload]
     precision = args.precision or wl["precision"]
