@@ -118,6 +118,7 @@ class ConvPre(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, in_slope, wp=None, wpt=None):
         x = x.contiguous()
+        ctx.set_materialize_grads(False)        # an unused output gradient stays None instead of a zero-filled tensor
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.in_slope, ctx.has_b = stride, in_slope, b is not None
         ctx.wp, ctx.wpt = wp, wpt
@@ -125,6 +126,8 @@ class ConvPre(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        if dz is None:
+            return None, None, None, None, None, None, None
         x, w = ctx.saved_tensors
         dz = dz.contiguous()
         dx = dw = db = None
@@ -141,6 +144,7 @@ class ConvDgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dz, w, x, stride, in_slope, wp=None, wpt=None):
         dz = dz.contiguous()
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(dz, w, x)
         ctx.stride, ctx.in_slope = stride, in_slope
         ctx.wp = wp
@@ -148,6 +152,8 @@ class ConvDgrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gdx):
+        if gdx is None:
+            return None, None, None, None, None, None, None
         dz, w, x = ctx.saved_tensors
         s = ctx.in_slope
         t = gdx.contiguous()
@@ -165,6 +171,7 @@ class ConvWgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dz, stride, in_slope):
         x, dz = x.contiguous(), dz.contiguous()
+        ctx.set_materialize_grads(False)        # the gradient penalty's double backward reaches dw only: ggb stays None
         ctx.save_for_backward(x, dz)
         ctx.stride, ctx.in_slope = stride, in_slope
         dw, db = conv_wgrad_raw(x, dz, stride, in_slope)
@@ -172,6 +179,8 @@ class ConvWgrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ggw, ggb):
+        if ggw is None and ggb is None:
+            return None, None, None, None
         x, dz = ctx.saved_tensors
         g_x = g_dz = None
         if ctx.needs_input_grad[0] and ggw is not None:
