@@ -48,47 +48,46 @@ def extract(data, etaBins, phiBins, channels=1):
     return img
 
 
+def _keep_where(x, keep):
+    """x with every entry outside the boolean mask ``keep`` set to zero."""
+    return x * keep.to(x.dtype)
+
+
 class ThresholdImageCutter:
-    """datasets.py:170-175."""
+    """Zeroes every pixel that does not exceed the energy threshold (datasets.py:170-175)."""
 
     def __init__(self, threshold):
         self.thres = threshold
 
     def __call__(self, x):
-        return torch.where(x > self.thres, x, torch.zeros_like(x))
+        return _keep_where(x, x > self.thres)
 
 
 class NHardestCutter:
-    """datasets.py:178-186, per image for batched input ([B, C, H, W]); a single image ([C, H, W] or [1, C, H, W]) behaves
-    as in the reference."""
+    """Keeps the N hardest (largest) pixels of an image, ties included, and zeroes the rest (datasets.py:178-186).  A batch
+    [B, C, H, W] with B > 1 is cut image by image; [C, H, W] / [1, C, H, W] is one image, as in the reference."""
 
     def __init__(self, N):
         self.N = N
 
     def __call__(self, x):
-        if x.dim() == 4 and x.shape[0] > 1:
-            flat = x.reshape(x.shape[0], -1)
-            highest = torch.sort(flat, 1)[0][:, -self.N].reshape(-1, 1, 1, 1)
-            return torch.where(x >= highest, x, torch.zeros_like(x))
-        highest = torch.sort(x.reshape(-1))[0][-self.N]
-        return torch.where(x >= highest, x, torch.zeros_like(x))
+        per_image = x.dim() == 4 and x.shape[0] > 1
+        flat = x.reshape(x.shape[0], -1) if per_image else x.reshape(1, -1)
+        nth = torch.topk(flat, self.N, dim=1).values[:, -1]               # the N-th largest value of each image
+        nth = nth.reshape(-1, 1, 1, 1) if per_image else nth.reshape(())
+        return _keep_where(x, x >= nth)
 
 
 class Cutter:
-    """datasets.py:189-201."""
+    """Dispatches to at most one of the two cutters (datasets.py:189-201); with neither it is the identity."""
 
     def __init__(self, thres=None, amount=None):
         if thres and amount:
             raise NotImplementedError("only one of thres and amount can be specified")
-        elif thres:
-            self.cutter = ThresholdImageCutter(thres)
-        elif amount:
-            self.cutter = NHardestCutter(amount)
-        else:
-            self.cutter = lambda x: x
+        self.cutter = ThresholdImageCutter(thres) if thres else (NHardestCutter(amount) if amount else None)
 
     def __call__(self, x):
-        return self.cutter(x)
+        return x if self.cutter is None else self.cutter(x)
 
 
 class _RowDataset(Dataset):

@@ -163,18 +163,21 @@ def _set_binedges(st, opt, nnz, info):
         parts = [None] * torch.distributed.get_world_size()
         torch.distributed.all_gather_object(parts, nnz)
         nnz = np.concatenate(parts)
-    for k in range(2):
-        if st.lambdas[k] > 0:
-            p = [1, opt.scaling_power][k]
-            c, b = np.histogram(nnz ** p, 100)
-            e_max = b[(np.cumsum(c) > len(nnz ** p) * .9).argmax()]
-            sorted_nnz = np.sort(nnz)
-            sorted_nnz = sorted_nnz[sorted_nnz <= e_max]
-            k_mean = KMeans(n_clusters=opt.bins, random_state=0).fit(sorted_nnz.reshape(-1, 1))
-            centers = np.sort(k_mean.cluster_centers_.flatten())
-            edges = np.array([0, *(np.diff(centers) / 2 + centers[:-1]), e_max])
-            info['binedges%i' % k] = list(edges)
-            st.set_hist_binedges(k, edges)
+    for k, power in enumerate((1, opt.scaling_power)):
+        if st.lambdas[k] <= 0:
+            continue
+        # upper edge: the left edge of the first of 100 equal bins at which the cumulative count passes 90 % of the values
+        values = nnz ** power
+        counts, bin_left = np.histogram(values, 100)
+        e_max = bin_left[np.argmax(np.cumsum(counts) > 0.9 * len(values))]
+        # bin centres: k-means (sklearn, random_state 0) over the un-powered values below e_max, as the reference clusters them;
+        # inner edges halfway between neighbouring centres (same arithmetic as the reference: the edges go into info.json)
+        below = np.sort(nnz)
+        below = below[below <= e_max]
+        centres = np.sort(KMeans(n_clusters=opt.bins, random_state=0).fit(below.reshape(-1, 1)).cluster_centers_.ravel())
+        edges = np.concatenate(([0.0], centres[:-1] + np.diff(centres) / 2, [e_max]))
+        info['binedges%i' % k] = list(edges)
+        st.set_hist_binedges(k, edges)
 
 
 def train(opt, **kwargs):

@@ -201,32 +201,32 @@ def soft_hist_all(x, centers, delta, sigma):
 
 
 class DiffableHistogram(nn.Module):
-    """models.py:308-342.  ``bins``: int (equal bins between min and max) or a sequence of bin edges.  ``forward(x)``
-    histograms ALL entries of x like the reference; the training step feeds it ``x[x > 0]`` -- use
-    :meth:`forward_positive` on the full tensor to get the same result without the gather."""
+    """Soft (sigmoid-edged) histogram, models.py:308-342.  ``bins``: an int (that many equal bins over [min, max]; like the
+    reference this yields bins - 1 centres) or a sequence of bin edges.  ``forward(x)`` histograms ALL entries of x like the
+    reference; the training step feeds it ``x[x > 0]`` -- :meth:`forward_positive` on the full tensor gives the same result
+    without the gather.  The counting itself is the fused kernel behind soft_hist_all / soft_hist_positive."""
 
     def __init__(self, bins, min=0, max=1, sigma=25, batchwise=False):
         super().__init__()
-        self.sigma = sigma
-        self.batchwise = batchwise
-        if type(bins) is int:
+        self.sigma, self.batchwise = sigma, batchwise
+        if isinstance(bins, int):
+            width = (max - min) / bins
             self.bins = torch.Tensor(bins)
-            self.delta = (max - min) / bins * torch.ones(bins - 1)
-            self.centers = float(min) + self.delta * (torch.arange(bins - 1).float() + 0.5)
+            self.delta = torch.full((bins - 1,), float(width))
+            self.centers = float(min) + width * (torch.arange(bins - 1, dtype=torch.float32) + 0.5)
         else:
-            self.bins = torch.as_tensor(np.asarray(bins, dtype=np.float32))
-            self.delta = torch.as_tensor(np.diff(np.asarray(bins, dtype=np.float64))[None, :]).float()
-            self.centers = self.bins[:-1] + .5 * self.delta
+            edges = np.asarray(bins)
+            self.bins = torch.as_tensor(edges.astype(np.float32))
+            self.delta = torch.as_tensor(np.diff(edges.astype(np.float64))).float().unsqueeze(0)
+            self.centers = self.bins[:-1] + self.delta / 2
 
-    def to(self, device):
-        self.centers = self.centers.to(device)
-        self.delta = self.delta.to(device)
+    def to(self, device):                      # plain attributes, not buffers (as in the reference): moved by hand
+        self.centers, self.delta = self.centers.to(device), self.delta.to(device)
         return self
 
     def forward(self, x):
-        batches = len(x) if (len(x.shape) == 4 and self.batchwise) else 1
-        if batches != 1:
-            return torch.cat([self.forward(xi.reshape(-1)) for xi in x], 0)
+        if self.batchwise and x.dim() == 4 and len(x) != 1:
+            return torch.cat([self.forward(img.reshape(-1)) for img in x], 0)
         return soft_hist_all(x.reshape(-1), self.centers, self.delta, self.sigma)
 
     def forward_positive(self, x):
@@ -234,14 +234,14 @@ class DiffableHistogram(nn.Module):
 
 
 class KLD_hist(nn.Module):
-    """utils.py:90-113: KL divergence between two (soft) histograms with bin-width weighting.  K-sized tensors: plain
-    torch ops."""
+    """KL(p || q) between two histograms given as bin COUNTS, every bin weighted by its width and the result divided by the
+    mean width (utils.py:90-113).  q gets +1e-6 per bin before normalising so that empty bins stay finite.  K-sized tensors:
+    plain torch ops."""
 
     def __init__(self, binedges):
         super().__init__()
-        binedges = torch.as_tensor(binedges)
-        binsizes = binedges[1:] - binedges[:-1]
-        self.binsizes = binsizes.float()
+        edges = torch.as_tensor(binedges)
+        self.binsizes = (edges[1:] - edges[:-1]).float()
         self.binmean = self.binsizes.mean()
         self.kldiv = nn.KLDivLoss(reduction='sum')
 
@@ -250,8 +250,6 @@ class KLD_hist(nn.Module):
         return self
 
     def forward(self, q_entries, p_entries):
-        N_p, N_q = p_entries.sum().float(), q_entries.sum().float()
-        p_entries = p_entries * self.binsizes / N_p
-        q_entries = q_entries + 1e-6
-        q_entries = (q_entries * self.binsizes / N_q).log()
-        return self.kldiv(q_entries, p_entries) / self.binmean
+        p = p_entries * self.binsizes / p_entries.sum().float()
+        log_q = ((q_entries + 1e-6) * self.binsizes / q_entries.sum().float()).log()
+        return self.kldiv(log_q, p) / self.binmean

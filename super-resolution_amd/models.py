@@ -60,13 +60,13 @@ class DenseResidualBlock(nn.Module):
         self.blocks = [self.b1, self.b2, self.b3, self.b4, self.b5]
 
     def forward(self, x):
-        inputs = x
-        for block in self.blocks:
-            out = block(inputs)
-            inputs = torch.cat([inputs, out], 1)
-        if self.drop:
-            out = self.drop1(out)
-        return out.mul(self.res_scale) + x
+        """Module-wise form (used by the drop_rate > 0 and ConvTranspose2d variants only): conv k sees x and the outputs of
+        convs 1..k-1 on the channel axis; the last conv's output, after the optional channel dropout, is the residual."""
+        feats = [x]
+        for conv_k in self.blocks:
+            feats.append(conv_k(feats[0] if len(feats) == 1 else torch.cat(feats, 1)))
+        residual = self.drop1(feats[-1]) if self.drop else feats[-1]
+        return torch.add(x, residual, alpha=self.res_scale)
 
 
 class ResidualInResidualDenseBlock(nn.Module):
@@ -80,7 +80,7 @@ class ResidualInResidualDenseBlock(nn.Module):
             DenseResidualBlock(filters, drop_rate=drop_rate))
 
     def forward(self, x):
-        return self.dense_blocks(x).mul(self.res_scale) + x
+        return torch.add(x, self.dense_blocks(x), alpha=self.res_scale)
 
 
 class GeneratorRRDB(nn.Module):

@@ -237,16 +237,17 @@ class Stepper:
         loss_D = (loss_real + loss_fake) / 2
         gp = None
         if self.lambda_reg > 0:
-            B = gt.shape[0]
+            # gradient penalty (esrgan.py:596-606): D's input gradient at a random point on the segment between each real
+            # image and its generated counterpart should have unit L2 norm; lambda_reg / 2 * mean((|g| - 1)^2).  The graph of
+            # that gradient is kept (create_graph): loss_D.backward() differentiates through it into D's weights.
+            n_img = gt.shape[0]
             if epsilon is None:
-                epsilon = torch.rand(B, 1, 1, 1, device=gt.device)
-            interpolation = epsilon * gt + (1 - epsilon) * gen_detached
-            interpolation.requires_grad = True
-            pred_interpolation = D(interpolation, cond)
-            gradients = torch.autograd.grad(outputs=pred_interpolation, inputs=interpolation, grad_outputs=valid,
-                                            create_graph=True, retain_graph=True, only_inputs=True)[0]
-            gradients = gradients.view(B, -1)
-            gp = ((gradients.norm(2, dim=1) - 1) ** 2).mean() * self.lambda_reg / 2
+                epsilon = torch.rand(n_img, 1, 1, 1, device=gt.device)
+            x_hat = (epsilon * gt + (1 - epsilon) * gen_detached).requires_grad_(True)
+            pred_hat = D(x_hat, cond)
+            (grad_hat,) = torch.autograd.grad(pred_hat, x_hat, grad_outputs=valid, create_graph=True, retain_graph=True)
+            grad_norm = grad_hat.reshape(n_img, -1).norm(2, dim=1)
+            gp = (grad_norm - 1).square().mean() * (self.lambda_reg / 2)
             loss_D = loss_D + gp
         return loss_D, gp
 
