@@ -705,15 +705,24 @@ __global__ __launch_bounds__(576) void conv3x3_f32_wino_kernel(const srk_conv_ar
 // 256 VGPRs each, and the 56 KB per 8-channel chunk (34x18 halo + 18 weight slices) go global -> LDS by DMA from the MFMA
 // waves themselves (7 instructions per wave and chunk), double-buffered, one barrier per chunk.  Needs in_slope == 1
 // (the DMA cannot apply the input LeakyReLU).
-template <int MODE>
-__global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_args a) {
-  constexpr int BN = 64, TH = 32, IH = TH + 2, IW = SRK_TW + 2;
+// NH = channel halves (32 output channels each) per workgroup.  NH = 2 (default): the 8-wave, 64-channel workgroup described
+// above, one per CU.  NH = 1 (SRK_WINO4_NH=1): a 4-wave, 32-channel workgroup (one wave per SIMD, 76 KB of LDS, <= 256 registers):
+// TWO independent workgroups share a CU, each SIMD hosts one wave of each, so the two waves of a SIMD no longer meet at one
+// barrier (with NH = 2 the older wave wins the matrix-pipe arbitration and waits ~2.6 k of 11.6 k cycles at the chunk barrier for
+// its partner) and the halo is staged twice per CU (78 instead of 56 KB of DMA per chunk).  Measured (stamps + GAN step, same
+// box): both workgroups are resident and finish 89-107 us apart instead of together, but the launch as a whole takes the same
+// time (138.3 vs 138.0 us per launch in the step) -- the matrix pipe is shared the same way either way.  Kept as the form a
+// two-stream schedule (two dependency chains per CU) would need; not the default.
+template <int MODE, int NH>
+__device__ __forceinline__ void wino4_body(const srk_conv_args& a) {
+  constexpr int BN = 32 * NH, TH = 32, IH = TH + 2, IW = SRK_TW + 2;
+  constexpr int NWV = 4 * NH;                      // waves per workgroup
   constexpr int NX4 = IH * IW * 2;                 // 1224 float4: [halo pixel][k-half]
   constexpr int NXI = (NX4 + 63) / 64;             // 20 wave-wide DMA instructions of halo (the last one: 8 live lanes)
   constexpr int NXP = NXI * 64;                    // halo region padded to whole instructions (1280 float4)
   constexpr int NW4 = 36 * BN;                     // 18 taps x 2 k-halves x BN
-  constexpr int NWI = NW4 / 64;                    // 36 instructions of weights
-  constexpr int BUF4 = NXP + NW4;                  // 3584 float4 = 57,344 B
+  constexpr int NWI = NW4 / 64;                    // 36 (NH = 2) / 18 (NH = 1) instructions of weights
+  constexpr int BUF4 = NXP + NW4;                  // 3584 float4 = 57,344 B (NH = 2) / 2432 float4 = 38,912 B (NH = 1)
   __shared__ float4 smem[2 * BUF4];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -737,11 +746,13 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const int nq = (a.Cin + 7) >> 3;
   SRK_STAMP_AT(0);
 
-  // ---- DMA plan.  Per chunk 20 halo + 36 weight instructions (1 KB each).  Piece j of a wave has a COMPILE-TIME kind so
-  // that issuing it is an m0 update + one buffer_load...lds: j = 0, 1 -> halo instruction wv + 8j; j = 2 -> halo 16 + wv
-  // (waves 0-3); j = 3..6 -> weight instruction wv + 8(j-3); j = 7 -> weight 32 + wv (waves 0-3).
+  // ---- DMA plan.  Per chunk NXI = 20 halo + NWI weight instructions (1 KB each), dealt to the waves in turn: piece j of a wave
+  // has a COMPILE-TIME kind so that issuing it is an m0 update + one buffer_load...lds: j < NXJ -> halo instruction wv + NWV j,
+  // else weight instruction wv + NWV (j - NXJ); the last piece of either kind exists for the low waves only.
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NPW = 8;
+  constexpr int NXJ = (NXI + NWV - 1) / NWV;       // halo pieces per wave: 3 (NH = 2) / 5 (NH = 1)
+  constexpr int NWJ = (NWI + NWV - 1) / NWV;       // weight pieces per wave: 5 / 5
+  constexpr int NPW = NXJ + NWJ;                   // 8 / 10
   const int Cps_in = a.Cin >> 2;
   long img_elems = (long)a.H * a.W * a.x_ldc;
   if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
@@ -750,12 +761,12 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
-  unsigned vo[4];
+  unsigned vo[NXJ + 1];
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = (j < 2 ? wv + 8 * j : 16 + wv) * 64 + lane;
+    for (int j = 0; j < NXJ; ++j) {
+      const int idx = (wv + NWV * j) * 64 + lane;
       unsigned v = OOB;
       if (idx < NX4) {
         const int hp = idx >> 1, half = idx & 1;
@@ -768,32 +779,34 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
       }
       vo[j] = v;
     }
-    // weight instruction i covers packed row th = i (BN = 64 lanes = 64 output channels): the lane part of the offset is
-    // the same for every piece, the row goes into the scalar offset
-    vo[3] = (n0 + lane < CoutP) ? (unsigned)((n0 + lane) * 16) : OOB;
+    // a weight instruction covers 64 / BN packed rows (th) of BN output channels: the lane part of the offset is the same for
+    // every piece, the first row of the instruction goes into the scalar offset
+    const int wrow = lane / BN, wch = lane - wrow * BN;
+    vo[NXJ] = (n0 + wch < CoutP) ? (unsigned)((wrow * CoutP + n0 + wch) * 16) : OOB;
   }
-  const bool low4 = wv < 4;
   auto piece = [&](int q, int b, auto jc) {
     constexpr int j = decltype(jc)::value;
+    static_assert(j < NPW, "piece index");
     if (q >= nq) return;
-    if ((j == 2 || j == 7) && !low4) return;
     float4* base = smem + b * BUF4;
-    if (j < 3) {
+    if (j < NXJ) {
+      const int i = wv + NWV * j;
+      if (NXJ * NWV > NXI && j == NXJ - 1 && i >= NXI) return;
       unsigned xso = (unsigned)(8 * q * 4);
       if (MODE == SRK_IN_UNSHUFFLE) {
         const int c8 = 8 * q;
         const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
         xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
       }
-      const int i = j < 2 ? wv + 8 * j : 16 + wv;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 64), 16, vo[j], xso, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + i * 64), 16, vo[j < NXJ ? j : 0], xso, 0, 0);
     } else {
-      const int i = j < 7 ? wv + 8 * (j - 3) : 32 + wv;
-      const unsigned wso = (unsigned)((q * 36 + i) * CoutP * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + NXP + i * 64), 16, vo[3], wso, 0, 0);
+      const int i = wv + NWV * (j - NXJ);
+      if (NWJ * NWV > NWI && j == NPW - 1 && i >= NWI) return;
+      const unsigned wso = (unsigned)((q * 36 + i * (64 / BN)) * CoutP * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + NXP + i * 64), 16, vo[NXJ], wso, 0, 0);
     }
   };
-  static_assert(NXI == 20 && NWI == 36, "piece schedule assumes 20 halo + 36 weight DMA instructions");
+  static_assert(NXI == 20 && (NWI == 36 || NWI == 18), "piece schedule assumes 20 halo + 36 / 18 weight DMA instructions");
 
   // ---- MFMA role
   const int wg = wv & 3, nh = wv >> 2;             // row group, output-channel half
@@ -841,13 +854,16 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
         if (e == 0) piece(dq, db, std::integral_constant<int, J0>{});
         if (e == 1) piece(dq, db, std::integral_constant<int, (NJ > 1 ? J0 + 1 : J0)>{});
         if (e == 2) piece(dq, db, std::integral_constant<int, (NJ > 2 ? J0 + 2 : J0)>{});
+        if (e == 3) piece(dq, db, std::integral_constant<int, (NJ > 3 ? J0 + 3 : J0)>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
   SRK_SEG_BEGIN();
-  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  using I5 = std::integral_constant<int, 5>;
+  // pieces 0-1 of a chunk go behind the previous chunk's last row, the other NPW - 2 behind rows 0 and 1, half each
+  constexpr int NJR = (NPW - 2) / 2;               // 3 (NH = 2) / 4 (NH = 1)
+  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, NJR>;
+  using I5 = std::integral_constant<int, 2 + NJR>;
   // chunk q sits in buffer b.  Chunk q+1 streams into b^1: its pieces 0-1 were issued behind the previous chunk's last
   // row, 2-7 go behind rows 0 and 1 here; after the barrier b is free and chunk q+2's pieces 0-1 go behind row 2.
   //
@@ -930,6 +946,7 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   piece(0, 0, std::integral_constant<int, 2>{}); piece(0, 0, std::integral_constant<int, 3>{});
   piece(0, 0, std::integral_constant<int, 4>{}); piece(0, 0, std::integral_constant<int, 5>{});
   piece(0, 0, std::integral_constant<int, 6>{}); piece(0, 0, std::integral_constant<int, 7>{});
+  if constexpr (NPW > 8) { piece(0, 0, std::integral_constant<int, (NPW > 8 ? 8 : 0)>{}); piece(0, 0, std::integral_constant<int, (NPW > 9 ? 9 : 0)>{}); }
   piece(1, 1, std::integral_constant<int, 0>{});
   piece(1, 1, std::integral_constant<int, 1>{});
   SRK_STAMP_AT(1);
@@ -951,7 +968,8 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
 #ifdef SRK_WINO4_NO_ROLES
   SRK_W4_LOOP(std::false_type)
 #else
-  if (nh == 0) SRK_W4_LOOP(std::false_type) else SRK_W4_LOOP(std::true_type)
+  if constexpr (NH == 1) SRK_W4_LOOP(std::false_type)        // (the two waves of a SIMD belong to different workgroups: no roles)
+  else if (nh == 0) SRK_W4_LOOP(std::false_type) else SRK_W4_LOOP(std::true_type)
 #endif
 #undef SRK_W4_LOOP
   SRK_SEG_END();
@@ -976,6 +994,13 @@ __global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_a
   SRK_STAMP_AT(4);
 }
 
+// The two launchable forms of the body above (thin kernels: the launch bounds differ, and a __global__ template over NH lost its
+// host-side launch stubs in this clang without any diagnostic).
+template <int MODE>
+__global__ __launch_bounds__(512) void conv3x3_f32_wino4_kernel(const srk_conv_args a) { wino4_body<MODE, 2>(a); }
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32_wino4h_kernel(const srk_conv_args a) { wino4_body<MODE, 1>(a); }   // 2 waves per SIMD = two workgroups per CU: at most 256 registers
+
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
 int launch_k(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, SRK_TH * MT);
@@ -998,11 +1023,19 @@ int launch_wino(const srk_conv_args& a, hipStream_t st) {
   return SRK_OK;
 }
 
+static int g_wino4_nh = -1;   // SRK_WINO4_NH = 1 | 2: channel halves per workgroup of the F(4,3) kernel (A/B measurements)
+
 template <int MODE>
 int launch_wino4(const srk_conv_args& a, hipStream_t st) {
   const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, 32);
-  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
-  hipLaunchKernelGGL((conv3x3_f32_wino4_kernel<MODE>), grid, dim3(512), 0, st, a);
+  if (g_wino4_nh < 0) { const char* e = getenv("SRK_WINO4_NH"); g_wino4_nh = e ? atoi(e) : 2; }
+  if (g_wino4_nh == 1) {
+    dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 32) / 32));
+    hipLaunchKernelGGL((conv3x3_f32_wino4h_kernel<MODE>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+    hipLaunchKernelGGL((conv3x3_f32_wino4_kernel<MODE>), grid, dim3(512), 0, st, a);
+  }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
@@ -1121,7 +1154,11 @@ extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_
   if (!pa || !buf || len < 8) return SRK_ERR_BAD_ARG;
   const srk_conv_args& a = *pa;
   if (a.wp_format == 1 || a.wp_format == 2) { snprintf(buf, len, "conv3x3_bf16x3_kernel<%d, %d>", a.in_mode, a.wp_format == 1 ? 3 : 1); return SRK_OK; }
-  if (a.wp_format == 5) { snprintf(buf, len, "conv3x3_f32_wino4_kernel<%d>", a.in_mode); return SRK_OK; }
+  if (a.wp_format == 5) {
+    if (g_wino4_nh < 0) { const char* e = getenv("SRK_WINO4_NH"); g_wino4_nh = e ? atoi(e) : 2; }
+    snprintf(buf, len, g_wino4_nh == 1 ? "conv3x3_f32_wino4h_kernel<%d>" : "conv3x3_f32_wino4_kernel<%d>", a.in_mode);
+    return SRK_OK;
+  }
   if (a.wp_format == 3) { snprintf(buf, len, "conv3x3_f32_wino_kernel<%d>", a.in_mode); return SRK_OK; }
   if (a.wp_format != 0) return SRK_ERR_UNSUPPORTED;
   if (const int small = srk_conv_small_kind(a)) {
@@ -1139,3 +1176,18 @@ extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_
   snprintf(buf, len, "conv3x3_f32_kernel<%d, %d, %d, %s, %d, false>", bn, a.stride, a.in_mode, vec ? "true" : "false", mt);
   return SRK_OK;
 }
+
+#ifdef SRK_STAMP
+// diagnostic build only: what the runtime says about residency of the two F(4,3) kernel forms
+extern "C" int srk_debug_occupancy(int* out4) {
+  int n = 0;
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, 0) != hipSuccess) return -5;
+  out4[2] = (int)pr.maxSharedMemoryPerMultiProcessor; out4[3] = (int)pr.sharedMemPerBlock;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_f32_wino4h_kernel<SRK_IN_PLAIN>, 256, 0) != hipSuccess) return -5;
+  out4[0] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_f32_wino4_kernel<SRK_IN_PLAIN>, 512, 0) != hipSuccess) return -5;
+  out4[1] = n;
+  return 0;
+}
+#endif
