@@ -15,6 +15,7 @@ echo "== update_g 2, d_threshold high"; python tools/train.py $COMMON --name ug 
 echo "== standard discriminator"; python tools/train.py $COMMON --name std --discriminator standard --d_channels 8 16 2>&1 | tail -1 | cut -c1-200
 echo "== non-relativistic"; python tools/train.py $COMMON --name nr --relativistic false 2>&1 | tail -1 | cut -c1-200
 echo "== drop_rate"; python tools/train.py $COMMON --name dr --drop_rate 0.2 2>&1 | tail -1 | cut -c1-200
+echo "== transposed-conv upsampling, n_checkpoints, save_late, reference option file keys"; echo '{"n_cpu": 0, "sample_interval": -1, "validation_interval": 1000, "evaluation_interval": 1000, "n_epochs": 20}' > $O/const.json; python tools/train.py $COMMON --name tc --factor 4 --use_transposed_conv true --n_checkpoints 3 --save_late 2 --default $O/const.json 2>&1 | tail -1 | cut -c1-200; ls $O/saved_models | grep -c "tc_"
 echo "== 3 channels, factor 4"; python tools/train.py --residual_blocks 1 --factor 4 --hr_height 32 --hr_width 48 --channels 3 --batch_size 2 --n_batches 4 --warmup_batches 1 --report_freq 1 --synthetic_batches 3 --dataset_type synthetic --root $O --name c3 2>&1 | tail -1 | cut -c1-200
 echo "== sparse jets from a .npy row table"
 python - <<'PY'
