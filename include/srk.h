@@ -238,7 +238,15 @@ int srk_conv3x3_fwd(const void* x, int ldc_in, int c_in_off, int Cin, const void
 int srk_conv3x3_dgrad(const void* dy, int ldc_dy, int c_dy_off, int Cout, const void* w, void* dx, int ldc_dx,
                       int c_dx_off, int Cin, int N, int H, int W, int stride, int pixel_shuffle_r, int dtype,
                       void* workspace, size_t ws_bytes, void* stream);
-/* (the weight gradient keeps the struct form above: srk_conv3x3_wgrad / srk_conv3x3_wgrad_batched) */
+/* Weight / bias gradient of the same convolution in flat form: dw [Cout,Cin,3,3] (canonical OIHW) and dbias [Cout] (may be
+ * NULL) from the conv input x [N,H,W,ldc_in] and the output gradient dy [N,ceil(H/stride),ceil(W/stride),ldc_dy]
+ * (pixel_shuffle_r = 2: dy is the gradient of the SHUFFLED output, [N,2H,2W,ldc_dy] with Cout/4 channels per pixel).
+ * dw = scale * sum (+ dw if accumulate).  Workspace: srk_workspace_bytes(SRK_OP_CONV_WGRAD, ...).  Deterministic (fixed-order
+ * split reduction, no float atomics).  Replaces the autograd weight gradient of nn.Conv2d, models.py:19,63,67,87,97,99,142-168. */
+int srk_conv3x3_wgrad_flat(const void* x, int ldc_in, int c_in_off, int Cin, const void* dy, int ldc_dy, int c_dy_off, int Cout,
+                           void* dw, void* dbias, int N, int H, int W, int stride, float scale, int accumulate,
+                           int pixel_shuffle_r, int dtype, void* workspace, size_t ws_bytes, void* stream);
+/* (srk_conv3x3_wgrad / srk_conv3x3_wgrad_batched above are the struct forms the engine uses: packed dense-block batches) */
 
 const char* srk_strerror(int status);
 int srk_version(void);

@@ -18,7 +18,7 @@ EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
-    "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad",
+    "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_jet_extract", "srk_strerror", "srk_version",
@@ -107,6 +107,8 @@ def lib():
                                       C.c_int, C.c_float, _fp, C.c_float, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
         L.srk_conv3x3_dgrad.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
+        L.srk_conv3x3_wgrad_flat.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]
         L.srk_jet_extract.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]
         L.srk_loss_workspace_bytes.argtypes = [C.POINTER(C.c_size_t)]
         L.srk_sigmoid_fwd.argtypes = [_fp, _fp, C.c_long, C.c_float, C.c_float, _fp]
@@ -308,6 +310,14 @@ def conv3x3_dgrad_flat(dy: "View", w, dx: "View", *, N, H, W, Cin, Cout, stride=
     ws = _workspace(workspace_bytes(OP_CONV_DGRAD, N, H, W, Cin, Cout), w.device)
     check(lib().srk_conv3x3_dgrad(dy.t.data_ptr(), dy.ldc, dy.coff, Cout, w.data_ptr(), dx.t.data_ptr(), dx.ldc, dx.coff, Cin,
                                   N, H, W, stride, ps, 0, ws.data_ptr(), ws.numel(), stream_ptr()), "srk_conv3x3_dgrad")
+
+
+def conv3x3_wgrad_flat(x: "View", dy: "View", dw, db, *, N, H, W, Cin, Cout, stride=1, scale=1.0, accumulate=False, ps=0):
+    """srk_conv3x3_wgrad_flat: weight / bias gradient into canonical OIHW tensors (H, W = extent of the conv input)."""
+    ws = _workspace(workspace_bytes(OP_CONV_WGRAD, N, H, W, Cin, Cout), dw.device)
+    check(lib().srk_conv3x3_wgrad_flat(x.t.data_ptr(), x.ldc, x.coff, Cin, dy.t.data_ptr(), dy.ldc, dy.coff, Cout, dw.data_ptr(), ptr(db),
+                                       N, H, W, stride, scale, int(accumulate), ps, 0, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "srk_conv3x3_wgrad_flat")
 
 
 def loss_workspace(device) -> torch.Tensor:

@@ -378,6 +378,28 @@ extern "C" int srk_conv3x3_dgrad(const void* dy, int ldc_dy, int c_dy_off, int C
   return srk_conv3x3(&a, stream);
 }
 
+extern "C" int srk_conv3x3_wgrad_flat(const void* x, int ldc_in, int c_in_off, int Cin, const void* dy, int ldc_dy, int c_dy_off, int Cout,
+                                      void* dw, void* dbias, int N, int H, int W, int stride, float scale, int accumulate,
+                                      int pixel_shuffle_r, int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !workspace) return SRK_ERR_BAD_ARG;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SRK_ERR_BAD_ARG;
+  if (dtype != 0 || (stride != 1 && stride != 2) || (pixel_shuffle_r != 0 && pixel_shuffle_r != 2)) return SRK_ERR_UNSUPPORTED;
+  if (pixel_shuffle_r == 2 && stride != 1) return SRK_ERR_UNSUPPORTED;
+  srk_wgrad_args a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.H = H; a.W = W; a.OH = srk_div_up(H, stride); a.OW = srk_div_up(W, stride); a.Cin = Cin; a.Cout = Cout; a.stride = stride;
+  a.dy_mode = pixel_shuffle_r == 2 ? SRK_IN_UNSHUFFLE : SRK_IN_PLAIN;
+  a.x = (const float*)x; a.x_ldc = ldc_in; a.x_coff = c_in_off; a.in_slope = 1.f;
+  a.dy = (const float*)dy; a.dy_ldc = ldc_dy; a.dy_coff = c_dy_off;
+  a.dw = (float*)dw; a.db = (float*)dbias; a.scale = scale; a.accumulate = accumulate;
+  a.workspace = workspace; a.workspace_bytes = ws_bytes;
+  size_t need = 0;
+  int rc = srk_conv3x3_wgrad_workspace(&a, &need);
+  if (rc) return rc;
+  if (ws_bytes < need) return SRK_ERR_WORKSPACE;
+  return srk_conv3x3_wgrad(&a, stream);
+}
+
 extern "C" const char* srk_strerror(int s) {
   switch (s) {
     case SRK_OK: return "ok";

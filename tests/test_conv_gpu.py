@@ -438,6 +438,28 @@ def test_flat_conv_dgrad(U, ci, co, h, w, n, stride, ps):
     assert U.rel_err(U.nchw(dx), x.grad) < TOL
 
 
+@pytest.mark.parametrize("ci,co,h,w,n,stride,ps", [(64, 64, 16, 16, 2, 1, 0), (320, 64, 12, 20, 1, 1, 0), (16, 32, 33, 20, 2, 2, 0),
+                                                   (1, 16, 32, 32, 2, 1, 0), (16, 64, 8, 12, 2, 1, 2), (64, 3, 9, 9, 1, 1, 0)])
+def test_flat_conv_wgrad(U, ci, co, h, w, n, stride, ps):
+    """srk_conv3x3_wgrad_flat: dw / dbias in canonical OIHW from strided channel slices, scale + accumulate."""
+    L = U.L
+    x = _rand((n, ci, h, w), 70)
+    wt = _rand((co, ci, 3, 3), 71, 1.0 / np.sqrt(9 * ci)).requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    y = O.conv3x3(x, wt, b, stride=stride)
+    if ps:
+        y = O.pixel_shuffle(y, 2)
+    g = _rand(y.shape, 72)
+    y.backward(g)
+    xb = U.nhwc(x, ldc=ci + 8, coff=4)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda"); db = torch.full((co,), float("nan"), device="cuda")
+    L.conv3x3_wgrad_flat(L.View(xb, 4, ci), L.View(U.nhwc(g)), dw, db, N=n, H=h, W=w, Cin=ci, Cout=co, stride=stride, ps=ps)
+    assert U.rel_err(dw.cpu(), wt.grad) < TOL and U.rel_err(db.cpu(), b.grad) < TOL
+    L.conv3x3_wgrad_flat(L.View(xb, 4, ci), L.View(U.nhwc(g)), dw, None, N=n, H=h, W=w, Cin=ci, Cout=co, stride=stride, ps=ps,
+                         scale=0.5, accumulate=True)
+    assert U.rel_err(dw.cpu(), 1.5 * wt.grad) < TOL
+
+
 def test_flat_workspace_and_errors(U):
     L = U.L
     import ctypes as C
