@@ -83,7 +83,9 @@ typedef struct srk_conv_args {
                                3: Winograd F(2,3)-along-W fp32 fragments (srk_pack_entry.fmt = 3): exact-fp32 MFMA on 2/3
                                   of the products; stride 1, Cin % 8 == 0, Cout % 64 == 0, plain / unshuffle input
                                5: Winograd F(4,3)-along-W fp32 fragments (fmt = 5): half of the products, 32x16 workgroup
-                                  tiles; as 3, plus in_slope == 1 */
+                                  tiles; as 3, plus in_slope == 1
+                               6: 2-D Winograd F(2x4, 3x3) fp32 fragments (fmt = 6): a third of the products (F(4,3) along W
+                                  times F(2,3) along H), 32x16 workgroup tiles, one wave per SIMD; same contract as 5 */
 } srk_conv_args;
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
@@ -156,7 +158,8 @@ typedef struct srk_pack_entry {
   int32_t fmt;              /* 0: fp32 fragments [K/8][tap][h][Mp][4];  1: split bf16 [K/16][tap][hi|lo][h][Mp][8]
                                (same byte size; k_off % 16 == 0);  3: Winograd fp32 fragments [K/8][3 rows x 4 pos][h][Mp][4]
                                with u = G w folded in (srk_pack_weights; 4/3 the size);  5: F(4,3) fragments [K/8][3 rows x 6 pos][h][Mp][4] (twice the
-                               size).  One table = one format. */
+                               size);  6: F(2x4, 3x3) fragments [K/8][4 channels][4 row x 6 column positions][h][Mp] floats (8/3
+                               the size).  One table = one format. */
   int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
 } srk_pack_entry;
 
@@ -169,6 +172,7 @@ int srk_pack_weights_bf16x3(const srk_pack_entry* device_entries, int n, int64_t
 size_t srk_packed_floats(int K, int M);   /* rounds K up to 16: valid for formats 0 and 1 */
 size_t srk_packed_floats_wino(int K, int M);   /* fmt 3: 12 transformed taps instead of 9 */
 size_t srk_packed_floats_wino4(int K, int M);  /* fmt 5: 18 transformed taps */
+size_t srk_packed_floats_wino42(int K, int M); /* fmt 6: 24 transformed taps */
 /* 1 if srk_conv3x3 accepts wp_format == 1 for this geometry (stride 1, Cin % 16 == 0, 16-byte addressable input) */
 int srk_conv3x3_bf16x3_supported(const srk_conv_args* a);
 

@@ -17,7 +17,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
-    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
+    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
@@ -84,6 +84,8 @@ def lib():
         L.srk_packed_floats_wino.argtypes = [C.c_int, C.c_int]
         L.srk_packed_floats_wino4.restype = C.c_size_t
         L.srk_packed_floats_wino4.argtypes = [C.c_int, C.c_int]
+        L.srk_packed_floats_wino42.restype = C.c_size_t
+        L.srk_packed_floats_wino42.argtypes = [C.c_int, C.c_int]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_debug_set_conv_small.argtypes = [C.c_int]
         L.srk_conv3x3_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]
@@ -328,6 +330,8 @@ def loss_workspace(device) -> torch.Tensor:
 
 def packed_floats(K: int, M: int, fmt: int = 0) -> int:
     """floats of the packed buffer for a (K inputs, M outputs) conv; fmt 3 (Winograd) carries 12 taps instead of 9."""
+    if fmt == 6:
+        return lib().srk_packed_floats_wino42(K, M)
     if fmt == 5:
         return lib().srk_packed_floats_wino4(K, M)
     return lib().srk_packed_floats_wino(K, M) if fmt == 3 else lib().srk_packed_floats(K, M)

@@ -1078,6 +1078,7 @@ int launch_bn(const srk_conv_args& a, hipStream_t st) {
 }  // namespace
 
 int srk_launch_conv_bf16x3(const srk_conv_args& a, hipStream_t st);
+int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st);      // srk_conv_w42.hip
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1102,6 +1103,15 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
     if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
     return srk_launch_conv_bf16x3(a, st);
+  }
+  if (a.wp_format == 6) {
+    // 2-D Winograd F(2x4, 3x3) fragments (fmt 6): same eligibility as format 5
+    if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
+    if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cout % 64) || (a.Cin % 8) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+    if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 8))) return SRK_ERR_UNSUPPORTED;
+    if ((a.x_ldc % 4) || (a.x_coff % 4) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
+    if (a.ps_out && (a.Cout & 3)) return SRK_ERR_BAD_ARG;
+    return srk_launch_conv_wino42(a, st);
   }
   if (a.wp_format == 5) {
     // Winograd F(4,3)-along-W fragments (fmt 5): as format 3, plus no input activation (staged by DMA)
@@ -1159,6 +1169,7 @@ extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_
     snprintf(buf, len, g_wino4_nh == 1 ? "conv3x3_f32_wino4h_kernel<%d>" : "conv3x3_f32_wino4_kernel<%d>", a.in_mode);
     return SRK_OK;
   }
+  if (a.wp_format == 6) { snprintf(buf, len, "conv3x3_f32_wino42_kernel<%d>", a.in_mode); return SRK_OK; }
   if (a.wp_format == 3) { snprintf(buf, len, "conv3x3_f32_wino_kernel<%d>", a.in_mode); return SRK_OK; }
   if (a.wp_format != 0) return SRK_ERR_UNSUPPORTED;
   if (const int small = srk_conv_small_kind(a)) {

@@ -1,0 +1,302 @@
+// srk_conv_w42.hip -- fused 3x3 convolution via the 2-D Winograd F(2x4, 3x3) ("wino42", wp_format 6) for gfx950.
+//
+// F(4,3) along the image row (as srk_conv.hip's wino4 kernel) TIMES F(2,3) along the column: an output patch of 2 rows x 4
+// columns comes from 4 x 6 = 24 products per (input, output) channel pair instead of 72 -- a THIRD of the direct kernel's
+// MFMAs (wino4: half).  fp32 throughout (v_mfma_f32_32x32x2_f32).
+//   rows  (F(2,3)):  p0 = d0 - d2, p1 = d1 + d2, p2 = d2 - d1, p3 = d1 - d3;     y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+//   cols  (F(4,3)):  v = B^T p, y = A^T m as in srk_conv.hip (Lavin & Gray);   u = G_h w G_w^T folded into the weight packing
+//
+// Shape of the kernel: the fp32 matrix pipe is slow (64 cycles per 32x32x2 MFMA), so ONE wave per SIMD has ~14 issue slots per
+// MFMA and the whole 512-entry register file: workgroup = 4 waves = 32 x 16 output pixels (64 patches = two 32-patch M tiles)
+// x 64 output channels x 24 positions = 96 accumulator tiles, 24 per wave (384 registers).  Wave w owns ROW POSITION p_w for
+// both M tiles and both channel halves, so
+//   * the input transform of a patch is computed once per workgroup (shared by the two channel halves),
+//   * every transformed-weight fragment is needed by exactly one wave: it is loaded global -> registers (buffer_load_dwordx2,
+//     all L2 hits) and never staged in LDS; only the 34 x 18 raw halo (20 KB per 8-channel chunk, 5 DMA pieces per wave) is,
+//   * the four row positions of a patch meet only once, after the K loop, through LDS (y0 / y1 above), which also re-deals the
+//     tiles so that every wave ends with the register layout conv_epilogue expects.
+// Per 8-channel chunk and wave: 96 MFMAs, 320 VALU (transform), 96 ds_read_b32, 48 buffer_load_dword, 5 DMA pieces, 1 barrier.
+#include "srk_internal.h"
+#include "srk_epilogue.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef SRK_STAMP
+__device__ unsigned long long* g_w42_stamps = nullptr;
+#define W42_STAMP(k) do { if (threadIdx.x == 0 && g_w42_stamps) g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W42_STAMP(k) do { } while (0)
+#endif
+
+// LDS image of the raw halo, per k-half h (4 channels = one float4 per pixel):
+//   slot(h, hy, hx) = 640 h + 18 hy + (hy >> 1) + hx          (34 rows x 18 pixels; one pad slot per row pair)
+// A lane reads, for its patch (row pair k, column quad t), pixels (2k + d, 4t + j): slot = 37 k + 4 t + const, and the M-tile
+// map below makes 37 k + 4 t distinct mod 16 over every 16-lane group of a ds_read_b128 and 2-uniform over the 32-lane groups
+// of a ds_read_b64 (the minimum) -- conflict-free reads although patches step by two rows and four pixels.
+template <int MODE>
+__device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
+  constexpr int TH = 32, IH = TH + 2, IW = SRK_TW + 2;
+  constexpr int HS4 = 640, BUF4 = 2 * HS4;          // 1280 float4 = 20 KB per chunk = 20 DMA instructions of 1 KB
+  constexpr int SMEM4 = 9216;                       // 144 KB: max(2 halo buffers, 128 KB of exchange + 4 x 4 KB epilogue scratch)
+  __shared__ float4 smem[SMEM4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // = row position p of this wave
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x;                        // XCD-contiguous tile ranges (see wino4_body)
+    if ((T & 7) == 0) bid = (bid & 7) * (T >> 3) + (bid >> 3);
+  }
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * TH, ow0 = tx * SRK_TW, n0 = blockIdx.y * 64;
+  const int CoutP = (a.Cout + 31) & ~31;
+  const int nq = (a.Cin + 7) >> 3;
+  W42_STAMP(0);
+
+  // ---- halo DMA plan: instruction i = wv + 4 j (j = 0..4) fills slots 64 i .. 64 i + 63
+  constexpr unsigned OOB = 0x80000000u;
+  const int Cps_in = a.Cin >> 2;
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const float* ximg = a.x + (long)n * img_elems;
+  const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
+  const unsigned wbytes = (unsigned)((long)nq * 192 * CoutP * 4);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  unsigned vo[5];
+  {
+    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int slot = (wv + 4 * j) * 64 + lane;
+      const int half = slot >= HS4 ? 1 : 0, p = slot - half * HS4;
+      const int R = p / 37, rem = p - R * 37;
+      const int hy = 2 * R + (rem >= 18 ? 1 : 0), hx = rem >= 18 ? rem - 18 : rem;
+      const int ih = ih0 + hy, iw = iw0 + hx;
+      unsigned v = OOB;
+      if (rem < 36 && hy < IH && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
+        long off;
+        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 4 * half;
+        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 4 * half;
+        v = (unsigned)(off * 4);
+      }
+      vo[j] = v;
+    }
+  }
+  // (a piece past the last chunk is issued with an out-of-range lane offset: nothing is read, zeros land in a buffer nobody reads)
+  auto piece = [&](int q, int b, auto jc) {
+    constexpr int j = decltype(jc)::value;
+    unsigned xso = (unsigned)(8 * q * 4);
+    if (MODE == SRK_IN_UNSHUFFLE) {
+      const int c8 = 8 * q;
+      const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
+      xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
+    }
+    const unsigned voff = q < nq ? vo[j] : OOB;
+    if (q >= nq) xso = 0;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + b * BUF4 + (wv + 4 * j) * 64), 16,
+                                             voff, xso, 0, 0);
+  };
+
+  // ---- operand addressing
+  // M index i = l32 = 8 q + 4 hb + s  ->  column quad t = hb + 2 (s & 1), row pair k = 8 mt + q + 4 (s >> 1)
+  const int mq = l32 >> 3, hb = (l32 >> 2) & 1, ms = l32 & 3;
+  const int tcol = hb + 2 * (ms & 1), krow = mq + 4 * (ms >> 1);
+  // raw rows of this wave's row position: p0 = d0 - d2, p1 = d1 + d2, p2 = d2 - d1, p3 = d1 - d3
+  const int da = wv == 0 ? 0 : (wv == 2 ? 2 : 1), db = wv == 3 ? 3 : (wv == 2 ? 1 : 2);
+  const float sgn = wv == 1 ? 1.f : -1.f;
+  const int slot0 = hl * HS4 + 37 * krow + 4 * tcol;
+  const float* ldsA = reinterpret_cast<const float*>(smem) + (slot0 + 18 * da + (da >> 1)) * 4;
+  const float* ldsB = reinterpret_cast<const float*>(smem) + (slot0 + 18 * db + (db >> 1)) * 4;
+  // weight fragments: [q][e][p][c][h][CoutP] floats; the lane part of the byte offset:
+  const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 4);
+  const unsigned sB_c = (unsigned)(2 * CoutP * 4);              // one column position
+  const unsigned sB_e = 24u * sB_c;                             // one channel of the chunk's k-halves
+
+  // 24 accumulator tiles: t = (2 mt + nh) 6 + c.  The compiler cannot split MFMA accumulators between the two register
+  // classes by itself (AGPR form for all: 384 > 256, whole tiles go to scratch), so the MFMAs are inline assembly with the
+  // class spelled out: tiles 0-15 live in a0-a255, tiles 16-23 in arch VGPRs, which leaves 128 VGPRs for the operands.
+  f32x16 acc[24];
+#pragma unroll
+  for (int t = 0; t < 24; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto mfma = [&](int t, float va, float vb) {       // t is a constant after unrolling: one of the two statements survives
+    if (t < 16) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(va), "v"(vb));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(va), "v"(vb));
+  };
+
+  float BX[6][2], BY[6][2], Vc[6], Vn[6], ra[6], rb[6];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+  using Yes = std::true_type; using No = std::false_type;
+
+  // One phase = 12 MFMAs of (channel e, M tile MT) on V / B.  In their shadow, placed by hand (one sched_barrier per MFMA):
+  //   slots 0-5   the NEXT phase's raw reads (two ds_read_b32 each) from buffer NB, M tile NMT, channel NE
+  //   slots 6-11  its row combination and F(4,3) column transform into VN
+  //   every slot  (LB) one weight load of channel (lq, le) into BN, resp. (slots 0-4, DMA) one halo piece of chunk dq
+  auto phase = [&](auto mtc, const float (&V)[6], const float (&B)[6][2], auto nbc, auto nmtc, auto nec, bool do_next, float (&VN)[6],
+                   auto lbc, int lq, int le, float (&BN)[6][2], auto dmac, int dq) {
+    constexpr int MT = decltype(mtc)::value;
+    constexpr int off = (decltype(nbc)::value * BUF4 + decltype(nmtc)::value * 296) * 4 + decltype(nec)::value;
+    constexpr bool LB = decltype(lbc)::value, DMA = decltype(dmac)::value;
+    constexpr int dbuf = decltype(nbc)::value ^ 1;       // the DMA goes into the buffer the barrier has just released
+    const unsigned so = (unsigned)(4 * lq + le) * sB_e + (unsigned)wv * 6u * sB_c;
+    float d0, d1, d2, d3, d4, d5, t1, t2, t3, t4, t5, t6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int c = i >> 1, nh = i & 1;
+      mfma((2 * MT + nh) * 6 + c, V[c], B[c][nh]);
+      if (LB) BN[c][nh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, vB + nh * 128, so + c * sB_c, 0));
+      if (DMA) {
+        if (i == 0) piece(dq, dbuf, I0{});
+        if (i == 1) piece(dq, dbuf, I1{});
+        if (i == 2) piece(dq, dbuf, I2{});
+        if (i == 3) piece(dq, dbuf, I3{});
+        if (i == 4) piece(dq, dbuf, I4{});
+      }
+      if (do_next) {
+        if (i < 6) { ra[i] = ldsA[off + 4 * i]; rb[i] = ldsB[off + 4 * i]; }
+        if (i == 6) { d0 = ra[0] + sgn * rb[0]; d1 = ra[1] + sgn * rb[1]; d2 = ra[2] + sgn * rb[2]; }
+        if (i == 7) { d3 = ra[3] + sgn * rb[3]; d4 = ra[4] + sgn * rb[4]; d5 = ra[5] + sgn * rb[5]; }
+        if (i == 8) { t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1; }
+        if (i == 9) { VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1; }
+        if (i == 10) { VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6; }
+        if (i == 11) { VN[5] = 4.f * d1 + (d5 - 5.f * d3); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Chunk q sits in buffer b:  (e, mt) = (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (3,0) | barrier | (3,1)
+  // weights of channel e + 1 are loaded during phase (e, 0) (BX / BY alternate).  At the barrier chunk q + 1 has landed in
+  // b ^ 1 and every wave has taken its last raw read of b; the last phase issues the DMA of chunk q + 2 -> b and forms the first
+  // V of chunk q + 1.
+  auto chunk = [&](int q, auto bc) {
+    constexpr int b = decltype(bc)::value;
+    using Bc = std::integral_constant<int, b>; using Bn = std::integral_constant<int, b ^ 1>;
+    const bool more = q + 1 < nq;
+    phase(I0{}, Vc, BX, Bc{}, I1{}, I0{}, true, Vn, Yes{}, q, 1, BY, No{}, 0);
+    phase(I1{}, Vn, BX, Bc{}, I0{}, I1{}, true, Vc, No{}, 0, 0, BY, No{}, 0);
+    phase(I0{}, Vc, BY, Bc{}, I1{}, I1{}, true, Vn, Yes{}, q, 2, BX, No{}, 0);
+    phase(I1{}, Vn, BY, Bc{}, I0{}, I2{}, true, Vc, No{}, 0, 0, BX, No{}, 0);
+    phase(I0{}, Vc, BX, Bc{}, I1{}, I2{}, true, Vn, Yes{}, q, 3, BY, No{}, 0);
+    phase(I1{}, Vn, BX, Bc{}, I0{}, I3{}, true, Vc, No{}, 0, 0, BY, No{}, 0);
+    phase(I0{}, Vc, BY, Bc{}, I1{}, I3{}, true, Vn, Yes{}, q + 1, 0, BX, No{}, 0);      // (past the end: out-of-range loads return 0)
+    // vector-memory operations retire in order: all but the 12 weight loads just issued = every DMA piece of chunk q + 1
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __syncthreads();
+    phase(I1{}, Vn, BY, Bn{}, I0{}, I0{}, more, Vc, No{}, 0, 0, BX, Yes{}, q + 2);
+  };
+
+  piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{}); piece(0, 0, I3{}); piece(0, 0, I4{});
+  piece(1, 1, I0{}); piece(1, 1, I1{}); piece(1, 1, I2{}); piece(1, 1, I3{}); piece(1, 1, I4{});
+  {
+    const unsigned so = (unsigned)wv * 6u * sB_c;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+        BX[c][nh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, vB + nh * 128, so + c * sB_c, 0));
+  }
+  W42_STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  W42_STAMP(2);
+  {
+    float d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d[j] = ldsA[4 * j] + sgn * ldsB[4 * j];
+    const float t1 = d[1] + d[2], t2 = d[4] + d[3], t3 = d[1] - d[2], t4 = d[4] - d[3], t5 = d[4] - d[2], t6 = d[3] - d[1];
+    Vc[0] = 4.f * d[0] + (d[4] - 5.f * d[2]); Vc[1] = t2 - 4.f * t1; Vc[2] = t4 + 4.f * t3;
+    Vc[3] = t5 + 2.f * t6; Vc[4] = t5 - 2.f * t6; Vc[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
+  }
+  {
+    int q = 0;
+    for (; q + 1 < nq; q += 2) {
+      chunk(q, I0{});
+      chunk(q + 1, I1{});
+    }
+    if (q < nq) chunk(q, I0{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (empty) DMA pieces and weight loads
+  __syncthreads();                                        // the exchange below reuses the halo buffers
+  // inline-assembly MFMAs are invisible to the compiler's hazard recogniser: the last ones must have left the pipe before VALU reads
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  W42_STAMP(3);
+
+  // ---- output transform + exchange.  Wave p holds m_p[mt][nh][c][reg]; reg = 4 q + s of lane half hb is patch
+  // (k = 8 mt + q + 4 (s >> 1), t = hb + 2 (s & 1)).  Column transform in registers (6 -> 4), then the four row positions are
+  // combined through LDS: wave f collects registers 4 f .. 4 f + 3 of every wave, which are exactly the rows 8 m + 2 f, + 1
+  // (m = 2 mt + (s >> 1)) of conv_epilogue's wave f.  Two passes (one per channel half): 128 KB of LDS each.
+  f32x16 out[4][2];
+  f32x4* ex = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[(2 * mt + nh) * 6 + 0][r], m1 = acc[(2 * mt + nh) * 6 + 1][r], m2 = acc[(2 * mt + nh) * 6 + 2][r], m3 = acc[(2 * mt + nh) * 6 + 3][r],
+                    m4 = acc[(2 * mt + nh) * 6 + 4][r], m5 = acc[(2 * mt + nh) * 6 + 5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        f32x4 z;
+        z[0] = (m0 + s12) + s34;
+        z[1] = d12 + 2.f * d34;
+        z[2] = s12 + 4.f * s34;
+        z[3] = (d12 + 8.f * d34) + m5;
+        const int f = r >> 2, s = r & 3;
+        ex[(((wv * 4 + f) * 2 + mt) * 4 + s) * 64 + lane] = z;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x4 z0 = ex[(((0 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane], z1 = ex[(((1 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane];
+        const f32x4 z2 = ex[(((2 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane], z3 = ex[(((3 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane];
+        const f32x4 y0 = (z0 + z1) + z2, y1 = (z1 - z2) - z3;
+        const int m = 2 * mt + (s >> 1), sx = s & 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          out[m][nh][4 * sx + c] = y0[c];
+          out[m][nh][4 * (sx + 2) + c] = y1[c];
+        }
+      }
+    if (nh == 0) __syncthreads();
+  }
+  W42_STAMP(4);
+  __builtin_amdgcn_sched_barrier(0);
+  conv_epilogue<64, 4, false, 16>(a, out, smem, n, oh0, ow0, n0, wv, lane, 32 + wv);
+  W42_STAMP(5);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_args a) { wino42_body<MODE>(a); }
+
+}  // namespace
+
+int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, 32);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+  if (a.in_mode == SRK_IN_PLAIN) hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_PLAIN>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_UNSHUFFLE>), grid, dim3(256), 0, st, a);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+
+#ifdef SRK_STAMP
+extern "C" int srk_debug_set_w42_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w42_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#endif

@@ -13,7 +13,7 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
   const int h = (int)(t & 1); t >>= 1;
-  const int ntap = e.fmt == 3 ? 12 : (e.fmt == 5 ? 18 : 9);
+  const int ntap = e.fmt == 3 ? 12 : (e.fmt == 5 ? 18 : (e.fmt == 6 ? 24 : 9));
   const int tap = (int)(t % ntap); t /= ntap;
   const int ql = (int)t;                      // chunk index relative to k_off/8
   const int q = (e.k_off >> 3) + ql;
@@ -35,7 +35,26 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
         if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
         w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
       }
-      if (e.fmt == 5) {
+      if (e.fmt == 6) {
+        // F(2x4, 3x3): 24 taps = 4 row positions (F(2,3): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 over the kernel ROWS) x 6 column
+        // positions (F(4,3) over the row's three column taps), u = G_h w G_w^T
+        const int rp = tap / 6, p = tap - 6 * rp;
+        float g[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          float c0, c1, c2;                       // column tap b of kernel rows 0, 1, 2 (data gradient: taps flipped)
+          if (!e.transpose) { c0 = w9[b]; c1 = w9[3 + b]; c2 = w9[6 + b]; }
+          else { c0 = w9[8 - b]; c1 = w9[5 - b]; c2 = w9[2 - b]; }
+          g[b] = rp == 0 ? c0 : rp == 1 ? 0.5f * ((c0 + c1) + c2) : rp == 2 ? 0.5f * ((c0 - c1) + c2) : c2;
+        }
+        const float w0 = g[0], w1 = g[1], w2 = g[2];
+        val = p == 0 ? 0.25f * w0
+            : p == 1 ? (-1.f / 6.f) * ((w0 + w1) + w2)
+            : p == 2 ? (-1.f / 6.f) * ((w0 - w1) + w2)
+            : p == 3 ? (w0 * (1.f / 24.f) + w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
+            : p == 4 ? (w0 * (1.f / 24.f) - w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
+            : w2;
+      } else if (e.fmt == 5) {
         // F(4,3): 18 taps = 3 kernel rows x 6 positions, u = G w
         const int r = tap / 6, p = tap - 6 * r;
         float w0, w1, w2;
@@ -59,6 +78,12 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
       val *= e.scale;
     }
     v[j] = val;
+  }
+  if (e.fmt == 6) {
+    // [q][channel j of the k-half][tap][h][Mp] floats: the wino42 kernel loads one channel's fragments at a time
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.dst[((((long)q * 4 + j) * 24 + tap) * 2 + h) * Mp + m] = v[j];
+    return;
   }
   float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * ntap + tap) * 2 + h) * Mp + m;
   *d = make_float4(v[0], v[1], v[2], v[3]);
@@ -196,13 +221,17 @@ extern "C" size_t srk_packed_floats_wino4(int K, int M) {
   return (size_t)srk_div_up(K, 16) * 2 * 18 * 2 * srk_round_up(M, 32) * 4;
 }
 
+extern "C" size_t srk_packed_floats_wino42(int K, int M) {
+  return (size_t)srk_div_up(K, 16) * 2 * 24 * 2 * srk_round_up(M, 32) * 4;
+}
+
 extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   if (!e || !total || n <= 0) return SRK_ERR_BAD_ARG;
   int64_t acc = 0;
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
-    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5 && e[i].fmt != 6)) return SRK_ERR_BAD_ARG;
     if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
     e[i].elem_begin = acc;
     // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
@@ -210,7 +239,7 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
     int k_end = e[i].k_off + e[i].k_len;
     int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
     // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
-    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : 9)) * 2 * srk_round_up(e[i].M, 32);
+    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : (e[i].fmt == 6 ? 24 : 9))) * 2 * srk_round_up(e[i].M, 32);
   }
   *total = acc;
   return SRK_OK;

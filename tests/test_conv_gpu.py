@@ -479,7 +479,7 @@ def test_flat_workspace_and_errors(U):
 # Winograd F(2,3)-along-W kernel (wp_format 3): same fused conv, 2/3 of the MFMAs; fp32 throughout
 @pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 64, 64, 2), (320, 64, 16, 16, 1), (8, 64, 9, 7, 2), (64, 128, 33, 17, 1),
                                          (128, 64, 20, 40, 1), (16, 64, 5, 3, 1), (64, 64, 1, 1, 1), (24, 192, 16, 31, 2)])
-@pytest.mark.parametrize("fmt", [3, 5])
+@pytest.mark.parametrize("fmt", [3, 5, 6])
 def test_wino_conv_fwd(U, ci, co, h, w, n, fmt):
     L = U.L
     x = _rand((n, ci, h, w), 71)
@@ -492,7 +492,7 @@ def test_wino_conv_fwd(U, ci, co, h, w, n, fmt):
     assert U.rel_err(U.nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("fmt", [3, 5])
+@pytest.mark.parametrize("fmt", [3, 5, 6])
 def test_wino_slices_residuals_mask_and_dgrad(U, fmt):
     """the dense-block addressing (channel prefix in, channel slice out, two residuals, alpha, LeakyReLU' mask) and the
     data gradient (transposed, tap-flipped weights through the same transform) on the Winograd kernel."""
@@ -523,7 +523,7 @@ def test_wino_slices_residuals_mask_and_dgrad(U, fmt):
     assert U.rel_err(U.nchw(dx), x.grad) < TOL
 
 
-@pytest.mark.parametrize("fmt", [3, 5])
+@pytest.mark.parametrize("fmt", [3, 5, 6])
 def test_wino_pixel_shuffle_fold_and_unshuffle(U, fmt):
     L = U.L
     n, F_, h, w = 2, 64, 8, 12
