@@ -318,7 +318,11 @@ def main():
             # The Winograd kernels execute fewer multiply-adds than the convolution's algorithmic count -- F(2,3) along W:
             # 4 instead of 6 per output pair (2/3); F(4,3): 6 instead of 12 per output quad (1/2) -- so the algorithmic-equivalent
             # rate (what a direct kernel would need to match the time) is reported beside it and may exceed the peak.
-            fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
+            # F(2x4,3x3) (wino42): 24 instead of 72 per 2x4 output patch (1/3)
+            if "wino42" in name:
+                fac, what = 1.0 / 3.0, "2-D Winograd F(2x4, 3x3): F(4,3) along W times F(2,3) along H"
+            else:
+                fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
             if "bf16x3" in name:      # template argument TERMS: 3 bf16 MFMAs per product (split operands) or 1 (plain bf16 operands)
                 terms = 3 if name.rstrip(">+reduce").rstrip(">").endswith("3") else 1
                 fac, what = float(terms), ("direct, %d bf16 MFMA%s per product, fp32 accumulate" % (terms, "s" if terms > 1 else ""))

@@ -158,7 +158,7 @@ typedef struct srk_pack_entry {
   int32_t fmt;              /* 0: fp32 fragments [K/8][tap][h][Mp][4];  1: split bf16 [K/16][tap][hi|lo][h][Mp][8]
                                (same byte size; k_off % 16 == 0);  3: Winograd fp32 fragments [K/8][3 rows x 4 pos][h][Mp][4]
                                with u = G w folded in (srk_pack_weights; 4/3 the size);  5: F(4,3) fragments [K/8][3 rows x 6 pos][h][Mp][4] (twice the
-                               size);  6: F(2x4, 3x3) fragments [K/8][4 channels][4 row x 6 column positions][h][Mp] floats (8/3
+                               size);  6: F(2x4, 3x3) fragments [K/8][2 channel pairs][4 row x 6 column positions][h][Mp][2] (8/3
                                the size).  One table = one format. */
   int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
 } srk_pack_entry;

@@ -347,7 +347,7 @@ class PackTable:
 
     def __init__(self, device, fmt=0):
         self.device = device
-        self.fmt = fmt               # 0: fp32 fragments, 1: split-bf16, 3 / 5: Winograd F(2,3) / F(4,3) fp32 fragments
+        self.fmt = fmt               # 0: fp32 fragments, 1: split-bf16, 3 / 5 / 6: Winograd F(2,3) / F(4,3) / F(2x4,3x3) fp32 fragments
         self.entries = []
         self._dev = None
         self._total = 0

@@ -15,7 +15,7 @@
 //     all L2 hits) and never staged in LDS; only the 34 x 18 raw halo (20 KB per 8-channel chunk, 5 DMA pieces per wave) is,
 //   * the four row positions of a patch meet only once, after the K loop, through LDS (y0 / y1 above), which also re-deals the
 //     tiles so that every wave ends with the register layout conv_epilogue expects.
-// Per 8-channel chunk and wave: 96 MFMAs, 320 VALU (transform), 96 ds_read_b32, 48 buffer_load_dword, 5 DMA pieces, 1 barrier.
+// Per 8-channel chunk and wave: 96 MFMAs, 160 VALU (transform), 48 ds_read_b64, 24 buffer_load_dwordx2, 5 DMA pieces, 1 barrier.
 #include "srk_internal.h"
 #include "srk_epilogue.h"
 #include <stdio.h>
@@ -29,9 +29,17 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef SRK_STAMP
 __device__ unsigned long long* g_w42_stamps = nullptr;
-#define W42_STAMP(k) do { if (threadIdx.x == 0 && g_w42_stamps) g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W42_STAMP(k) do { if (threadIdx.x == 0 && g_w42_stamps) { g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define W42_SEG_BEGIN() unsigned long long seg_t = __builtin_amdgcn_s_memtime(); unsigned long long seg_sum[9] = {0,0,0,0,0,0,0,0,0}
+#define W42_SEG_RESET() do { seg_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define W42_SEG(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_sum[k] += t_ - seg_t; seg_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W42_SEG_END() do { if (lane == 0 && g_w42_stamps) for (int k_ = 0; k_ < 9; ++k_) g_w42_stamps[(4096 + (blockIdx.x + gridDim.x * blockIdx.y) * 4 + wv) * 16 + k_] = seg_sum[k_]; } while (0)
 #else
 #define W42_STAMP(k) do { } while (0)
+#define W42_SEG_BEGIN() do { } while (0)
+#define W42_SEG_RESET() do { } while (0)
+#define W42_SEG(k) do { } while (0)
+#define W42_SEG_END() do { } while (0)
 #endif
 
 // LDS image of the raw halo, per k-half h (4 channels = one float4 per pixel):
@@ -70,7 +78,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
   const float* ximg = a.x + (long)n * img_elems;
   const unsigned xbytes = (unsigned)(img_elems * 4 > 0x7fffffffL ? 0x7fffffffL : img_elems * 4);
-  const unsigned wbytes = (unsigned)((long)nq * 192 * CoutP * 4);
+  const unsigned wbytes = (unsigned)((long)nq * 96 * CoutP * 8);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
   unsigned vo[5];
@@ -118,109 +126,136 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const int slot0 = hl * HS4 + 37 * krow + 4 * tcol;
   const float* ldsA = reinterpret_cast<const float*>(smem) + (slot0 + 18 * da + (da >> 1)) * 4;
   const float* ldsB = reinterpret_cast<const float*>(smem) + (slot0 + 18 * db + (db >> 1)) * 4;
-  // weight fragments: [q][e][p][c][h][CoutP] floats; the lane part of the byte offset:
-  const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 4);
-  const unsigned sB_c = (unsigned)(2 * CoutP * 4);              // one column position
-  const unsigned sB_e = 24u * sB_c;                             // one channel of the chunk's k-halves
+  // weight fragments: [q][e-pair][p][c][h][CoutP] float2; the lane part of the byte offset:
+  const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 8);
+  const unsigned sB_c = (unsigned)(2 * CoutP * 8);              // one column position
+  const unsigned sB_ep = 24u * sB_c;                            // one channel pair of the chunk's k-halves
 
-  // 24 accumulator tiles: t = (2 mt + nh) 6 + c.  The compiler cannot split MFMA accumulators between the two register
-  // classes by itself (AGPR form for all: 384 > 256, whole tiles go to scratch), so the MFMAs are inline assembly with the
-  // class spelled out: tiles 0-15 live in a0-a255, tiles 16-23 in arch VGPRs, which leaves 128 VGPRs for the operands.
   f32x16 acc[24];
-#pragma unroll
-  for (int t = 0; t < 24; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   auto mfma = [&](int t, float va, float vb) {       // t is a constant after unrolling: one of the two statements survives
+    // HAZARD: a VALU result needs two wait states before an MFMA may read it, and the compiler's hazard recogniser does not look
+    // into inline assembly.  The schedule below forms every operand at least one MFMA slot ahead of its use and the main loop is
+    // branch-free (one basic block: nothing is sunk next to its use); tools/check_w42_hazards.py verifies the generated code.
+    // (an s_nop 1 inside the asm costs 12-14 cycles per MFMA: the slots are issue-bound)
     if (t < 16) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(va), "v"(vb));
     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(va), "v"(vb));
   };
 
-  float BX[6][2], BY[6][2], Vc[6], Vn[6], ra[6], rb[6];
+  f32x2 P0[6][2], P1[6][2];          // weights of channels (0,1) resp. (2,3) of the chunk's k-halves: [c][nh]
+  float Vc[6], Vn[6];
+  f32x2 ra[6], rb[6];                // raw pixels of the current group: rows a / b of this wave's row position, a channel pair each
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using IN = std::integral_constant<int, -1>;
   using Yes = std::true_type; using No = std::false_type;
 
-  // One phase = 12 MFMAs of (channel e, M tile MT) on V / B.  In their shadow, placed by hand (one sched_barrier per MFMA):
-  //   slots 0-5   the NEXT phase's raw reads (two ds_read_b32 each) from buffer NB, M tile NMT, channel NE
-  //   slots 6-11  its row combination and F(4,3) column transform into VN
-  //   every slot  (LB) one weight load of channel (lq, le) into BN, resp. (slots 0-4, DMA) one halo piece of chunk dq
-  auto phase = [&](auto mtc, const float (&V)[6], const float (&B)[6][2], auto nbc, auto nmtc, auto nec, bool do_next, float (&VN)[6],
-                   auto lbc, int lq, int le, float (&BN)[6][2], auto dmac, int dq) {
-    constexpr int MT = decltype(mtc)::value;
-    constexpr int off = (decltype(nbc)::value * BUF4 + decltype(nmtc)::value * 296) * 4 + decltype(nec)::value;
-    constexpr bool LB = decltype(lbc)::value, DMA = decltype(dmac)::value;
-    constexpr int dbuf = decltype(nbc)::value ^ 1;       // the DMA goes into the buffer the barrier has just released
-    const unsigned so = (unsigned)(4 * lq + le) * sB_e + (unsigned)wv * 6u * sB_c;
+  // One phase = 12 MFMAs of (channel E of the k-halves, M tile MT) on V / B.  The phases of a chunk come in four GROUPS
+  // (channel pair, M tile): the raw pixels of a group are read ONCE as channel pairs (ds_read_b64: half the LDS instructions of
+  // dword reads and a 2-way instead of a 4-way bank conflict -- with dword reads the LDS cost 13 cycles of issue each, 1300 per
+  // chunk).  In the shadow of the MFMAs, placed by hand (one sched_barrier per MFMA):
+  //   first phase of a group   slots 0-5: row combination + F(4,3) column transform of the pair's SECOND channel into VN
+  //   second phase of a group  slots 0-5: the NEXT group's raw reads (buffer NB, M tile NMT, pair NP; two ds_read_b64 each),
+  //                            slots 6-11: its first channel's transform into VN
+  //   every slot  (LB) one weight load (dwordx2: a channel pair) of pair lp of chunk lq into BN
+  //   slot 11     (DJ >= 0) halo piece DJ of chunk dq into buffer DB: one gather per phase, so that a piece never queues behind
+  //               the previous one in the address unit (five in a row cost ~180 cycles each)
+  auto phase = [&](auto mtc, auto ec, const float (&V)[6], const f32x2 (&B)[6][2], auto secondc, auto nbc, auto nmtc, auto npc,
+                   float (&VN)[6], auto lbc, int lq, int lp, f32x2 (&BN)[6][2], auto djc, int dq, auto dbc) {
+    constexpr int MT = decltype(mtc)::value, E = decltype(ec)::value & 1;
+    constexpr bool SECOND = decltype(secondc)::value;
+    constexpr int off = (decltype(nbc)::value * BUF4 + decltype(nmtc)::value * 296) * 4 + 2 * decltype(npc)::value;
+    constexpr bool LB = decltype(lbc)::value;
+    constexpr int DJ = decltype(djc)::value, DB = decltype(dbc)::value;
+    constexpr int X0 = SECOND ? 6 : 0, COMP = SECOND ? 0 : 1;       // transform: first slot, channel of the pair
+    const unsigned so = (unsigned)(2 * lq + lp) * sB_ep + (unsigned)wv * 6u * sB_c;
     float d0, d1, d2, d3, d4, d5, t1, t2, t3, t4, t5, t6;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int c = i >> 1, nh = i & 1;
-      mfma((2 * MT + nh) * 6 + c, V[c], B[c][nh]);
-      if (LB) BN[c][nh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, vB + nh * 128, so + c * sB_c, 0));
-      if (DMA) {
-        if (i == 0) piece(dq, dbuf, I0{});
-        if (i == 1) piece(dq, dbuf, I1{});
-        if (i == 2) piece(dq, dbuf, I2{});
-        if (i == 3) piece(dq, dbuf, I3{});
-        if (i == 4) piece(dq, dbuf, I4{});
+      mfma((2 * MT + nh) * 6 + c, V[c], B[c][nh][E]);
+#ifndef W42_NO_LB
+      if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
+#endif
+#ifndef W42_NO_DMA
+      if (DJ >= 0 && i == 11) piece(dq, DB, std::integral_constant<int, (DJ >= 0 ? DJ : 0)>{});
+#endif
+      if (SECOND && i < 6) {
+        ra[i] = *reinterpret_cast<const f32x2*>(ldsA + off + 4 * i);
+        rb[i] = *reinterpret_cast<const f32x2*>(ldsB + off + 4 * i);
       }
-      if (do_next) {
-        if (i < 6) { ra[i] = ldsA[off + 4 * i]; rb[i] = ldsB[off + 4 * i]; }
-        if (i == 6) { d0 = ra[0] + sgn * rb[0]; d1 = ra[1] + sgn * rb[1]; d2 = ra[2] + sgn * rb[2]; }
-        if (i == 7) { d3 = ra[3] + sgn * rb[3]; d4 = ra[4] + sgn * rb[4]; d5 = ra[5] + sgn * rb[5]; }
-        if (i == 8) { t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1; }
-        if (i == 9) { VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1; }
-        if (i == 10) { VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6; }
-        if (i == 11) { VN[5] = 4.f * d1 + (d5 - 5.f * d3); }
-      }
+      if (i == X0 + 0) { d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP]; }
+      if (i == X0 + 1) { d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP]; }
+      if (i == X0 + 2) { t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1; }
+      if (i == X0 + 3) { VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1; }
+      if (i == X0 + 4) { VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6; }
+      if (i == X0 + 5) { VN[5] = 4.f * d1 + (d5 - 5.f * d3); }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // Chunk q sits in buffer b:  (e, mt) = (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (3,0) | barrier | (3,1)
-  // weights of channel e + 1 are loaded during phase (e, 0) (BX / BY alternate).  At the barrier chunk q + 1 has landed in
-  // b ^ 1 and every wave has taken its last raw read of b; the last phase issues the DMA of chunk q + 2 -> b and forms the first
-  // V of chunk q + 1.
+  W42_SEG_BEGIN();
+  // Chunk q sits in buffer b:  (e, mt) = (0,0) (1,0) | (0,1) (1,1) | (2,0) (3,0) | (2,1) | barrier | (3,1)
+  //   weights: P1 <- pair 1 of chunk q during (0,0), P0 <- pair 0 of chunk q + 1 during (2,0): four phases ahead of their use
+  //   halo:    pieces 1-4 of chunk q + 1 -> b ^ 1 behind the first four phases; at the barrier chunk q + 1 has landed and every
+  //            wave has taken its last raw read of b; piece 0 of chunk q + 2 -> b behind (3,1), which also reads the first group
+  //            of chunk q + 1 and forms its first V.
   auto chunk = [&](int q, auto bc) {
     constexpr int b = decltype(bc)::value;
     using Bc = std::integral_constant<int, b>; using Bn = std::integral_constant<int, b ^ 1>;
-    const bool more = q + 1 < nq;
-    phase(I0{}, Vc, BX, Bc{}, I1{}, I0{}, true, Vn, Yes{}, q, 1, BY, No{}, 0);
-    phase(I1{}, Vn, BX, Bc{}, I0{}, I1{}, true, Vc, No{}, 0, 0, BY, No{}, 0);
-    phase(I0{}, Vc, BY, Bc{}, I1{}, I1{}, true, Vn, Yes{}, q, 2, BX, No{}, 0);
-    phase(I1{}, Vn, BY, Bc{}, I0{}, I2{}, true, Vc, No{}, 0, 0, BX, No{}, 0);
-    phase(I0{}, Vc, BX, Bc{}, I1{}, I2{}, true, Vn, Yes{}, q, 3, BY, No{}, 0);
-    phase(I1{}, Vn, BX, Bc{}, I0{}, I3{}, true, Vc, No{}, 0, 0, BY, No{}, 0);
-    phase(I0{}, Vc, BY, Bc{}, I1{}, I3{}, true, Vn, Yes{}, q + 1, 0, BX, No{}, 0);      // (past the end: out-of-range loads return 0)
-    // vector-memory operations retire in order: all but the 12 weight loads just issued = every DMA piece of chunk q + 1
+    phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
+    W42_SEG(0);
+    phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I1{}, I0{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
+    W42_SEG(1);
+    phase(I1{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, No{}, 0, 0, P1, I3{}, q + 1, Bn{});
+    W42_SEG(2);
+    phase(I1{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I4{}, q + 1, Bn{});
+    W42_SEG(3);
+    phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (past the end: out-of-range loads return 0)
+    W42_SEG(4);
+    phase(I0{}, I3{}, Vn, P1, Yes{}, Bc{}, I1{}, I1{}, Vc, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    W42_SEG(5);
+    phase(I1{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    W42_SEG(6);
+    // vector-memory operations retire in order: all but the 12 weight loads of (2,0) = every DMA piece of chunk q + 1
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __syncthreads();
-    phase(I1{}, Vn, BY, Bn{}, I0{}, I0{}, more, Vc, No{}, 0, 0, BX, Yes{}, q + 2);
+    W42_SEG(7);
+    phase(I1{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)
+    W42_SEG(8);
   };
 
   piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{}); piece(0, 0, I3{}); piece(0, 0, I4{});
-  piece(1, 1, I0{}); piece(1, 1, I1{}); piece(1, 1, I2{}); piece(1, 1, I3{}); piece(1, 1, I4{});
   {
     const unsigned so = (unsigned)wv * 6u * sB_c;
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
-        BX[c][nh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, vB + nh * 128, so + c * sB_c, 0));
+        P0[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
   }
   W42_STAMP(1);
+  __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
+#pragma unroll
+  for (int t = 0; t < 24; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   W42_STAMP(2);
   {
     float d[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) d[j] = ldsA[4 * j] + sgn * ldsB[4 * j];
+    for (int j = 0; j < 6; ++j) {
+      ra[j] = *reinterpret_cast<const f32x2*>(ldsA + 4 * j);
+      rb[j] = *reinterpret_cast<const f32x2*>(ldsB + 4 * j);
+      d[j] = ra[j][0] + sgn * rb[j][0];
+    }
     const float t1 = d[1] + d[2], t2 = d[4] + d[3], t3 = d[1] - d[2], t4 = d[4] - d[3], t5 = d[4] - d[2], t6 = d[3] - d[1];
     Vc[0] = 4.f * d[0] + (d[4] - 5.f * d[2]); Vc[1] = t2 - 4.f * t1; Vc[2] = t4 + 4.f * t3;
     Vc[3] = t5 + 2.f * t6; Vc[4] = t5 - 2.f * t6; Vc[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
   }
+  piece(1, 1, I0{});           // (the state every chunk starts in: piece 0 of the next chunk in flight)
+  W42_SEG_RESET();
   {
     int q = 0;
     for (; q + 1 < nq; q += 2) {
@@ -229,6 +264,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     }
     if (q < nq) chunk(q, I0{});
   }
+  W42_SEG_END();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (empty) DMA pieces and weight loads
   __syncthreads();                                        // the exchange below reuses the halo buffers
   // inline-assembly MFMAs are invisible to the compiler's hazard recogniser: the last ones must have left the pipe before VALU reads

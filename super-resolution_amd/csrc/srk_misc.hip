@@ -80,9 +80,10 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
     v[j] = val;
   }
   if (e.fmt == 6) {
-    // [q][channel j of the k-half][tap][h][Mp] floats: the wino42 kernel loads one channel's fragments at a time
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e.dst[((((long)q * 4 + j) * 24 + tap) * 2 + h) * Mp + m] = v[j];
+    // [q][channel pair of the k-half][tap][h][Mp] float2: the wino42 kernel loads a channel pair's fragments at a time
+    float2* d2 = reinterpret_cast<float2*>(e.dst);
+    d2[((((long)q * 2 + 0) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[0], v[1]);
+    d2[((((long)q * 2 + 1) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[2], v[3]);
     return;
   }
   float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * ntap + tap) * 2 + h) * Mp + m;

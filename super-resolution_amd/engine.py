@@ -183,8 +183,8 @@ class GeneratorEngine:
         F_, C_ = g.filters, g.channels
         self.flat_f, self.flat_b = _Flat(), _Flat()
         # one table per (direction, fragment format)
-        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3, 5)}
-        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3, 5)}
+        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6)}
+        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6)}
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
         bf = self.precision in ("bf16x3", "bf16")
@@ -194,6 +194,8 @@ class GeneratorEngine:
         wino = (not bf) and os.environ.get("SRK_WINOGRAD", "1") != "0"
 
         wino4 = wino and os.environ.get("SRK_WINOGRAD4", "1") != "0"
+        # the same tiles through the 2-D F(2x4, 3x3) kernel (a third instead of half of the MFMAs); SRK_WINOGRAD42=0: F(4,3)
+        w4fmt = 6 if os.environ.get("SRK_WINOGRAD42", "1") != "0" else 5
 
         def fmt_of(K, M, up=1):
             """fragment format of a conv with K inputs, M outputs running at `up` x the LR resolution"""
@@ -203,7 +205,7 @@ class GeneratorEngine:
                 return 0
             # F(4,3) works on 32 x 16 tiles, one 8-wave workgroup per CU: worth it when those tiles fill the chip and do not
             # pad the image more than the 16 x 16 tiles of the F(2,3) kernel would
-            return 5 if (wino4 and self._wino4_ok(geo, up, M // 64)) else 3
+            return w4fmt if (wino4 and self._wino4_ok(geo, up, M // 64)) else 3
 
         def simple(name, conv, ps=False, need_bwd=True, up=1):
             co, ci = conv.weight.shape[:2]
@@ -214,7 +216,7 @@ class GeneratorEngine:
             bi = None
             if need_bwd:
                 fb = fmt_of(co, ci, up) if (not ps or (co // 4) % 16 == 0) else 0
-                if fb in (3, 5) and conv.stride[0] != 1:
+                if fb in (3, 5, 6) and conv.stride[0] != 1:
                     fb = 0
                 bi = self.flat_b.reserve(L.packed_floats(co, ci, fb))
                 self.fmt_b[bi] = fb
