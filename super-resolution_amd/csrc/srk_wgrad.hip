@@ -575,6 +575,243 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 2-D Winograd weight gradient ("wino22"): the transposed F(2,3) algorithm in BOTH image directions.  A 2 x 2 patch of dy and
+// the 4 x 4 patch of x around it give the nine taps from 16 products instead of 36 (the 1-D kernel above: 24):
+//     U = A g A^T (4 x 4 from the 2 x 2 dy patch),  V = B^T d B (4 x 4 from the x patch),  M_pq += U_pq V_pq  over all patches,
+//     dW = G^T M G  once, at the end          (A, B, G: the 1-D matrices of the kernel above, applied along columns then rows)
+// i.e. 4/9 of the direct kernel's MFMAs (1-D: 2/3).  The MFMA K index runs over PATCHES.
+// Shape: like the wino42 conv kernel, ONE wave per SIMD: workgroup = 4 waves = one 64 x 64 (cout, cin) chunk, wave (wa, wb) =
+// one 32 x 32 tile x 16 positions = 16 accumulator tiles (all 256 AGPRs); the operands of a k-step (two patches) are formed in
+// registers from 4 + 16 raw LDS dwords per lane (44 VALU per 16 MFMAs), one step ahead, in the shadow of the MFMAs.  Pixel tiles
+// of 8 rows x 16 columns (+ halo) go global -> LDS by DMA, two buffers; the tile barrier sits in front of the LAST k-step, whose
+// shadow already prepares the first step of the next tile from the other buffer.
+constexpr int W22_TH = 8;
+constexpr int W22_TP = W22_TH * WTW;                       // 128 dy pixels
+constexpr int W22_IH = W22_TH + 2, W22_IW = WTW + 2;       // 10 x 18 halo
+constexpr int W22_NHP = W22_IH * W22_IW;                   // 180
+constexpr int W22_TILE_FLOATS = (W22_TP + W22_NHP) * 64;   // 19,712 floats = 78,848 B per buffer
+constexpr int W22_THREADS = 256;
+
+template <int DYMODE>
+__global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBatch B, float* part, float* pbias) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 157,696 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int wa = wv & 1, wb = wv >> 1;
+  int p, chunk;
+  {
+    const int id = blockIdx.x, nc = B.n_chunks, pm = B.P & ~7;      // XCD-aware placement, as in wgrad_f32_wino_kernel
+    if (id < pm * nc) { const int s_ = id >> 3; p = (id & 7) + 8 * (s_ / nc); chunk = s_ - (s_ / nc) * nc; }
+    else { const int r_ = id - pm * nc; p = pm + r_ / nc; chunk = r_ - (r_ / nc) * nc; }
+  }
+  const int pi = __builtin_amdgcn_readfirstlane(B.c_prob[chunk]);
+  const int cy = __builtin_amdgcn_readfirstlane(B.c_cy[chunk]), cz = __builtin_amdgcn_readfirstlane(B.c_cz[chunk]);
+  const WProb& a = B.prob[pi];
+  const int cin0 = cy * 64, cout0 = cz * 64;
+  const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
+  const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
+  const int Cps = a.Cout >> 2;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const int t_begin = p * B.tpb;
+  int t_end = t_begin + B.tpb;
+  if (t_end > B.total_tiles) t_end = B.total_tiles;
+
+  const long x_img = (long)B.H * B.W * a.x_ldc;
+  const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
+  const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
+  const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
+  const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
+  constexpr int NPIECE = (W22_TP + W22_NHP) * 16;                  // 16-byte pieces per tile: 2048 (dy) + 2880 (x)
+  constexpr int NINST = NPIECE / 64;                               // 77 wave-wide DMA instructions per tile
+  static_assert(NPIECE % 64 == 0, "whole DMA instructions");
+  constexpr int NDY = W22_TP * 16 / 64;                            // 32 of them are dy
+  // a DMA instruction moves 4 consecutive pixels x 16 channel quads (1 KB, 8 cache lines)
+  const int c4 = lane & 15, lp = lane >> 4;
+  const int co = cout0 + 4 * c4, ci = cin0 + 4 * c4;
+  int dyc, dyij = 0;
+  if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
+  const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
+  constexpr int NPW = (NINST + 3) / 4;                             // 20 pieces per wave and tile (wave 0: 20, others 19)
+  struct TileCtx { int oh0, ow0; __amdgpu_buffer_rsrc_t xr, dr; };
+  auto tile_ctx = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % B.tilesW; tt /= B.tilesW;
+    const int ty = tt % B.tilesH; tt /= B.tilesH;
+    const int n = tt;
+    TileCtx c;
+    c.oh0 = ty * W22_TH; c.ow0 = tx * WTW;
+    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
+    return c;
+  };
+  // piece j of this wave = instruction 4 j + wv of the tile (`live`: wave-uniform)
+  auto piece = [&](const TileCtx& c, int b, int j, bool live) {
+    const int i = j * 4 + wv;
+    if (i >= NINST || !live) return;                               // (i >= NINST: only j = NPW - 1 of waves 1-3)
+    float* buf = smem + b * W22_TILE_FLOATS;
+    if (i < NDY) {
+      const int oh = c.oh0 + (i >> 2), ow = c.ow0 + 4 * (i & 3) + lp;   // pixel 4i + lp of the 8 x 16 tile
+      unsigned off;
+      if (DYMODE == SRK_IN_UNSHUFFLE) off = (unsigned)((((2 * oh + (dyij >> 1)) * (2 * B.OW) + 2 * ow + (dyij & 1)) * a.dy_ldc + dyc) * 4);
+      else off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + dyc) * 4);
+      const bool ok = oh < B.OH && ow < B.OW && co_ok;
+      wdma16(c.dr, buf + i * 256, ok ? off : W_OOB);
+    } else {
+      const int hp = 4 * (i - NDY) + lp;                           // halo pixel 0..179
+      const int hy = hp / W22_IW, hx = hp - hy * W22_IW;
+      const int ih = c.oh0 - 1 + hy, iw = c.ow0 - 1 + hx;
+      const bool ok = ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci_ok;
+      const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
+      wdma16(c.xr, buf + i * 256, ok ? off : W_OOB);
+    }
+  };
+
+  // per-lane LDS offsets (floats): k-step kk = patch row kk >> 2, patch columns 2 (kk & 3) + hl
+  const int aoff = (2 * hl) * 64 + 32 * wa + l32;                              // dy pixel (0, 2 hl)
+  const int boff = W22_TP * 64 + (2 * hl) * 64 + 32 * wb + l32;                // halo pixel (0, 2 hl)
+
+  float U0[16], V0[16], U1[16], V1[16], g[4], d[16];
+  // raw operands of k-step kk of the tile in buffer bb
+  auto ld_raw = [&](int bb, int kk) {
+    const float* ap = smem + bb * W22_TILE_FLOATS + aoff + ((2 * (kk >> 2)) * 16 + 4 * (kk & 3)) * 64;
+    const float* bp = smem + bb * W22_TILE_FLOATS + boff + ((2 * (kk >> 2)) * W22_IW + 4 * (kk & 3)) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) g[2 * i + j] = ap[(i * 16 + j) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[4 * i + j] = bp[(i * W22_IW + j) * 64];
+  };
+  // the 44 VALU operations of the operand transform, in 11 groups of 4 (one group per MFMA slot)
+  float a01, a02, a11, a12, bq[16];
+  auto xform = [&](int grp, float (&U)[16], float (&V)[16], bool count_bias) {
+    if (grp == 0) { a01 = g[0] + g[1]; a02 = g[0] - g[1]; a11 = g[2] + g[3]; a12 = g[2] - g[3]; }
+    if (grp == 1) { U[4] = g[0] + g[2]; U[5] = a01 + a11; U[6] = a02 + a12; U[7] = g[1] + g[3]; }
+    if (grp == 2) {
+      U[8] = g[0] - g[2]; U[9] = a01 - a11; U[10] = a02 - a12; U[11] = g[1] - g[3];
+      U[0] = g[0]; U[1] = a01; U[2] = a02; U[3] = g[1]; U[12] = g[2]; U[13] = a11; U[14] = a12; U[15] = g[3];
+      if (do_bias) bsum += count_bias ? a01 + a11 : 0.f;        // (the operands formed behind the last tile are not real)
+    }
+    if (grp >= 3 && grp <= 6) {
+      const int r = grp - 3;
+      bq[4 * r + 0] = d[4 * r + 0] - d[4 * r + 2]; bq[4 * r + 1] = d[4 * r + 1] + d[4 * r + 2];
+      bq[4 * r + 2] = d[4 * r + 2] - d[4 * r + 1]; bq[4 * r + 3] = d[4 * r + 1] - d[4 * r + 3];
+    }
+    if (grp == 7) { for (int q = 0; q < 4; ++q) V[q] = bq[q] - bq[8 + q]; }
+    if (grp == 8) { for (int q = 0; q < 4; ++q) V[4 + q] = bq[4 + q] + bq[8 + q]; }
+    if (grp == 9) { for (int q = 0; q < 4; ++q) V[8 + q] = bq[8 + q] - bq[4 + q]; }
+    if (grp == 10) { for (int q = 0; q < 4; ++q) V[12 + q] = bq[4 + q] - bq[12 + q]; }
+  };
+  // One k-step = 16 MFMAs on (U, V); in their shadow, by hand (one sched_barrier per MFMA): slots 0-4 the raw reads of the NEXT
+  // step (buffer nb, step nk), slots 5-15 its transform into (UN, VN); slots 7 and 15: one DMA piece each of tile `dt` into `db`
+  auto kstep = [&](const float (&U)[16], const float (&V)[16], int nb, int nk, float (&UN)[16], float (&VN)[16],
+                   const TileCtx& dc, int db, int dj, bool dlive, bool next_real) {
+    const float* ap = smem + nb * W22_TILE_FLOATS + aoff + ((2 * (nk >> 2)) * 16 + 4 * (nk & 3)) * 64;
+    const float* bp = smem + nb * W22_TILE_FLOATS + boff + ((2 * (nk >> 2)) * W22_IW + 4 * (nk & 3)) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[i], V[i], acc[i], 0, 0, 0);
+      if (i == 0) { g[0] = ap[0]; g[1] = ap[64]; g[2] = ap[16 * 64]; g[3] = ap[17 * 64]; }
+      if (i >= 1 && i <= 4) {
+        const int r = i - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
+      }
+      if (i >= 5) xform(i - 5, UN, VN, next_real);
+      if (dj >= 0 && i == 7) piece(dc, db, 2 * dj, dlive);
+      if (dj >= 0 && i == 15) piece(dc, db, 2 * dj + 1, dlive);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (t_begin < t_end) {
+    const TileCtx c0 = tile_ctx(t_begin);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) piece(c0, 0, j, true);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+  __syncthreads();
+  if (t_begin < t_end) {
+    if (t_begin + 1 < t_end) {                                     // (the state every tile starts in: pieces 0, 1 of the next one issued)
+      const TileCtx c1 = tile_ctx(t_begin + 1);
+      piece(c1, 1, 0, true); piece(c1, 1, 1, true);
+    }
+    ld_raw(0, 0);
+#pragma unroll
+    for (int grp = 0; grp < 11; ++grp) xform(grp, U0, V0, true);
+  }
+  int b = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    // tile sits in buffer b, tile + 1 is in flight into b ^ 1 (issued during the previous tile); tile + 2 goes into b once the
+    // barrier in front of the last k-step has released it: its pieces ride on that step and on steps 0-8 of the next tile.
+    const bool more1 = tile + 1 < t_end;
+    const TileCtx cn = tile_ctx(more1 ? tile + 1 : tile);          // (the tile whose pieces 2-19 are issued during THIS tile's steps 0-8)
+    const bool livep = more1;
+    const int bnp = b ^ 1;
+#pragma unroll
+    for (int kk = 0; kk < 14; kk += 2) {
+      kstep(U0, V0, b, kk + 1, U1, V1, cn, bnp, kk < 9 ? kk + 1 : -1, livep, true);
+      kstep(U1, V1, b, kk + 2, U0, V0, cn, bnp, kk + 1 < 9 ? kk + 2 : -1, livep, true);
+    }
+    kstep(U0, V0, b, 15, U1, V1, cn, bnp, -1, false, true);        // k-step 14
+    __builtin_amdgcn_s_waitcnt(0x0070);                            // every piece of tile + 1 has landed (no other VMEM in flight)
+    __builtin_amdgcn_s_barrier();
+    {
+      const bool more2 = tile + 2 < t_end;
+      const TileCtx c2 = tile_ctx(more2 ? tile + 2 : tile);
+      kstep(U1, V1, bnp, 0, U0, V0, c2, b, 0, more2, more1);       // k-step 15: pieces 0, 1 of tile + 2; first operands of tile + 1
+    }
+    b ^= 1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+
+  // G^T M G: taps from the 4 x 4 positions (columns q first, then rows p)
+  f32x16 tap[9];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float T[4][3];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const float m0 = acc[4 * pp][e], m1 = acc[4 * pp + 1][e], m2 = acc[4 * pp + 2][e], m3 = acc[4 * pp + 3][e];
+      const float hs = 0.5f * (m1 + m2);
+      T[pp][0] = m0 + hs; T[pp][1] = 0.5f * (m1 - m2); T[pp][2] = hs - m3;
+    }
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const float hs = 0.5f * (T[1][sx] + T[2][sx]);
+      tap[sx][e] = T[0][sx] + hs;
+      tap[3 + sx][e] = 0.5f * (T[1][sx] - T[2][sx]);
+      tap[6 + sx][e] = hs - T[3][sx];
+    }
+  }
+  if (active) {
+    float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+        dst[(t * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = tap[t][reg];
+      }
+  }
+  if (do_bias) {
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Split-bf16 ("bf16x3") weight gradient, opt-in (srk_wgrad_args.precision = 1), stride 1.
 // Same decomposition as above (workgroup = one 64x64x9 chunk, wave (a,b) = nine 32x32 tiles, K = pixels) on
 // v_mfma_f32_32x32x16_bf16 with operands split x = hi + lo:  dy*x ~= dy_hi*x_hi + dy_hi*x_lo + dy_lo*x_hi (fp32
@@ -969,10 +1206,7 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
       }
   }
   B.n_chunks = nc;
-  const int TH = a0.stride == 1 ? WGeo<1>::TH : WGeo<2>::TH;
-  B.tilesW = srk_div_up(a0.OW, WTW);
-  B.tilesH = srk_div_up(a0.OH, TH);
-  B.total_tiles = a0.N * B.tilesH * B.tilesW;
+  int TH = a0.stride == 1 ? WGeo<1>::TH : WGeo<2>::TH;
   // ~2 workgroups per CU.  (A/B on one box, full GAN iteration: 512 -> 273.1 ms, 256 -> 276.7 ms for the 1-2 chunk
   // problems: the second workgroup per CU hides more than the extra partial-sum traffic costs.)
   static int small_target = -1;
@@ -985,6 +1219,13 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   B.wino = wino_env && a0.stride == 1 && a0.precision == 0;
   for (int i = 0; i < n; ++i)
     B.wino = B.wino && is_vec(args[i]) && args[i].in_slope == 1.f && args[i].Cout > 32 && args[i].Cin > 32 && args[i].precision == 0;
+  // 2-D form (wino22, 8-row tiles, 4 waves): SRK_WGRAD_WINO22=0 keeps the 1-D kernel
+  static int wino22_env = -1;
+  if (wino22_env < 0) { const char* e = getenv("SRK_WGRAD_WINO22"); wino22_env = e ? atoi(e) : 1; }
+  if (B.wino && wino22_env) { B.wino = 2; TH = W22_TH; }
+  B.tilesW = srk_div_up(a0.OW, WTW);
+  B.tilesH = srk_div_up(a0.OH, TH);
+  B.total_tiles = a0.N * B.tilesH * B.tilesW;
   int target = (nc <= 2 ? small_target : 512) / nc;
   if (B.wino) target = 256 / nc;
   if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
@@ -1060,7 +1301,9 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     if (ks_env < 0) { const char* e = getenv("SRK_WGRAD_KSPLIT"); ks_env = e ? atoi(e) : 1; }
     if (!ks_env) ksp = 1;
   }
-  if (S == 1 && VEC && B.wino)
+  if (S == 1 && VEC && B.wino == 2)
+    hipLaunchKernelGGL((wgrad_f32_wino22_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(W22_THREADS), 0, st, B, part, pbias);
+  else if (S == 1 && VEC && B.wino)
     hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(WW_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 4)
     hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
@@ -1146,6 +1389,7 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
   if (a0.precision == 1 || a0.precision == 2) { snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d>", a0.dy_mode, a0.precision == 1 ? 3 : 1); return SRK_OK; }
+  if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d>", a0.dy_mode); return SRK_OK; }
   if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
   int ksp = 1;
   if (a0.dy_mode == SRK_IN_PLAIN) {
