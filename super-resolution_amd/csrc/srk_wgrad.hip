@@ -589,12 +589,12 @@ constexpr int W22_TH = 8;
 constexpr int W22_TP = W22_TH * WTW;                       // 128 dy pixels
 constexpr int W22_IH = W22_TH + 2, W22_IW = WTW + 2;       // 10 x 18 halo
 constexpr int W22_NHP = W22_IH * W22_IW;                   // 180
-constexpr int W22_TILE_FLOATS = (W22_TP + W22_NHP) * 64;   // 19,712 floats = 78,848 B per buffer
+constexpr int W22_TILE_FLOATS = 80 * 256;                  // (128 + 180) pixels x 64 channels, padded to 80 DMA slots: 81,920 B per buffer
 constexpr int W22_THREADS = 256;
 
 template <int DYMODE>
 __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBatch B, float* part, float* pbias) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 157,696 B
+  __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 163,840 B: all of the LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = lane >> 5, l32 = lane & 31;
@@ -629,107 +629,129 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
   const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
   const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
   const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
-  constexpr int NPIECE = (W22_TP + W22_NHP) * 16;                  // 16-byte pieces per tile: 2048 (dy) + 2880 (x)
-  constexpr int NINST = NPIECE / 64;                               // 77 wave-wide DMA instructions per tile
-  static_assert(NPIECE % 64 == 0, "whole DMA instructions");
-  constexpr int NDY = W22_TP * 16 / 64;                            // 32 of them are dy
-  // a DMA instruction moves 4 consecutive pixels x 16 channel quads (1 KB, 8 cache lines)
+  // ---- DMA plan.  A wave-wide instruction moves 4 consecutive pixels x 16 channel quads (1 KB, 8 cache lines): 32 of dy,
+  // 45 of x per tile, 80 slots (the tile buffer is padded to 80 KB so that all four waves own exactly 20: instruction 4 j + wv).
+  // Everything that depends on the lane is computed ONCE: the byte offset of the piece relative to the tile origin and its
+  // column relative to the tile origin.  Issuing a piece is then 6 instructions, none of them a branch (the k-steps stay ONE
+  // basic block, so the hand-placed order below survives): rows outside the image fall out of the per-image buffer range by
+  // themselves (negative offsets wrap), only the column needs a test.
+  constexpr int NDY = W22_TP * 16 / 64;                            // 32 dy instructions
+  constexpr int NINST = NDY + W22_NHP * 16 / 64;                   // 77 live instructions
+  constexpr int NPW = 20;
+  static_assert(NDY % 4 == 0 && NINST <= 4 * NPW && 4 * NPW * 256 <= W22_TILE_FLOATS, "DMA slots");
   const int c4 = lane & 15, lp = lane >> 4;
   const int co = cout0 + 4 * c4, ci = cin0 + 4 * c4;
   int dyc, dyij = 0;
   if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
   const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
-  constexpr int NPW = (NINST + 3) / 4;                             // 20 pieces per wave and tile (wave 0: 20, others 19)
-  struct TileCtx { int oh0, ow0; __amdgpu_buffer_rsrc_t xr, dr; };
+  unsigned rel[NPW];
+  int colx[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int i = 4 * j + wv;
+    if (j < NDY / 4) {
+      const int r = i >> 2, c = 4 * (i & 3) + lp;                  // pixel 4i + lp of the 8 x 16 tile
+      if (DYMODE == SRK_IN_UNSHUFFLE) rel[j] = (unsigned)((((2 * r + (dyij >> 1)) * (2 * B.OW) + 2 * c + (dyij & 1)) * a.dy_ldc + dyc) * 4);
+      else rel[j] = (unsigned)(((r * B.OW + c) * a.dy_ldc + dyc) * 4);
+      colx[j] = co_ok ? c : -(1 << 20);
+    } else {
+      const int hp = 4 * (i - NDY) + lp;                           // halo pixel 0..179 (beyond: the padding slots)
+      const int hy = hp / W22_IW, hx = hp - hy * W22_IW;
+      rel[j] = (unsigned)((((hy - 1) * B.W + (hx - 1)) * a.x_ldc + ci) * 4);
+      colx[j] = (ci_ok && i < NINST) ? hx - 1 : -(1 << 20);
+    }
+  }
+  struct TileCtx { int ow0; unsigned org_dy, org_x; __amdgpu_buffer_rsrc_t xr, dr; };
   auto tile_ctx = [&](int tile) {
     int tt = tile;
     const int tx = tt % B.tilesW; tt /= B.tilesW;
     const int ty = tt % B.tilesH; tt /= B.tilesH;
     const int n = tt;
     TileCtx c;
-    c.oh0 = ty * W22_TH; c.ow0 = tx * WTW;
+    const int oh0 = ty * W22_TH;
+    c.ow0 = tx * WTW;
+    c.org_dy = (unsigned)((DYMODE == SRK_IN_UNSHUFFLE ? (2 * oh0 * 2 * B.OW + 2 * c.ow0) : (oh0 * B.OW + c.ow0)) * a.dy_ldc * 4);
+    c.org_x = (unsigned)((oh0 * B.W + c.ow0) * a.x_ldc * 4);
     c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
     c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
     return c;
   };
-  // piece j of this wave = instruction 4 j + wv of the tile (`live`: wave-uniform)
+  // piece j of this wave (j: compile-time after unrolling); `live` false (wave-uniform): issued out of range -- nothing is read,
+  // zeros land in a buffer nobody reads any more
   auto piece = [&](const TileCtx& c, int b, int j, bool live) {
-    const int i = j * 4 + wv;
-    if (i >= NINST || !live) return;                               // (i >= NINST: only j = NPW - 1 of waves 1-3)
-    float* buf = smem + b * W22_TILE_FLOATS;
-    if (i < NDY) {
-      const int oh = c.oh0 + (i >> 2), ow = c.ow0 + 4 * (i & 3) + lp;   // pixel 4i + lp of the 8 x 16 tile
-      unsigned off;
-      if (DYMODE == SRK_IN_UNSHUFFLE) off = (unsigned)((((2 * oh + (dyij >> 1)) * (2 * B.OW) + 2 * ow + (dyij & 1)) * a.dy_ldc + dyc) * 4);
-      else off = (unsigned)(((oh * B.OW + ow) * a.dy_ldc + dyc) * 4);
-      const bool ok = oh < B.OH && ow < B.OW && co_ok;
-      wdma16(c.dr, buf + i * 256, ok ? off : W_OOB);
-    } else {
-      const int hp = 4 * (i - NDY) + lp;                           // halo pixel 0..179
-      const int hy = hp / W22_IW, hx = hp - hy * W22_IW;
-      const int ih = c.oh0 - 1 + hy, iw = c.ow0 - 1 + hx;
-      const bool ok = ih >= 0 && iw >= 0 && ih < B.H && iw < B.W && ci_ok;
-      const unsigned off = (unsigned)(((ih * B.W + iw) * a.x_ldc + ci) * 4);
-      wdma16(c.xr, buf + i * 256, ok ? off : W_OOB);
-    }
+    float* dst = smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256;
+    const bool isdy = j < NDY / 4;
+    const unsigned off = rel[j] + (isdy ? c.org_dy : c.org_x);
+    const bool ok = live && (unsigned)(colx[j] + c.ow0) < (unsigned)(isdy ? B.OW : B.W);
+    wdma16(isdy ? c.dr : c.xr, dst, ok ? off : W_OOB);
   };
 
-  // per-lane LDS offsets (floats): k-step kk = patch row kk >> 2, patch columns 2 (kk & 3) + hl
+  // per-lane LDS offsets (floats) of patch (row 0, columns 2 * 0 + hl)
   const int aoff = (2 * hl) * 64 + 32 * wa + l32;                              // dy pixel (0, 2 hl)
   const int boff = W22_TP * 64 + (2 * hl) * 64 + 32 * wb + l32;                // halo pixel (0, 2 hl)
 
-  float U0[16], V0[16], U1[16], V1[16], g[4], d[16];
-  // raw operands of k-step kk of the tile in buffer bb
-  auto ld_raw = [&](int bb, int kk) {
-    const float* ap = smem + bb * W22_TILE_FLOATS + aoff + ((2 * (kk >> 2)) * 16 + 4 * (kk & 3)) * 64;
-    const float* bp = smem + bb * W22_TILE_FLOATS + boff + ((2 * (kk >> 2)) * W22_IW + 4 * (kk & 3)) * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) g[2 * i + j] = ap[(i * 16 + j) * 64];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[4 * i + j] = bp[(i * W22_IW + j) * 64];
+  // K-step order: DOWN the patch columns, kk = 4 * (column pair) + (patch row).  Vertically adjacent patches share two of their
+  // four x rows, so for patch rows 1-3 only the two new rows are read and column-transformed (12 instead of 20 LDS dwords, 36
+  // instead of 44 VALU per step); the transformed rows 2, 3 of the previous step are carried in registers as rows 0, 1.
+  float U0[16], V0[16], U1[16], V1[16], d[16];
+  auto raw_ptrs = [&](int bb, int kk, const float*& ap, const float*& bp) {
+    const int pr = kk & 3, cp = kk >> 2;
+    ap = smem + bb * W22_TILE_FLOATS + aoff + ((2 * pr) * 16 + 4 * cp) * 64;
+    bp = smem + bb * W22_TILE_FLOATS + boff + ((2 * pr) * W22_IW + 4 * cp) * 64;
   };
-  // the 44 VALU operations of the operand transform, in 11 groups of 4 (one group per MFMA slot)
-  float a01, a02, a11, a12, bq[16];
-  auto xform = [&](int grp, float (&U)[16], float (&V)[16], bool count_bias) {
-    if (grp == 0) { a01 = g[0] + g[1]; a02 = g[0] - g[1]; a11 = g[2] + g[3]; a12 = g[2] - g[3]; }
-    if (grp == 1) { U[4] = g[0] + g[2]; U[5] = a01 + a11; U[6] = a02 + a12; U[7] = g[1] + g[3]; }
+  // the VALU operations of the operand transform in groups of 4 (one group per MFMA slot).  The four dy values are loaded
+  // straight into U[0], U[3], U[12], U[15] (the corner positions ARE the raw values); the column-transformed x rows live in two
+  // register sets that swap roles from patch row to patch row (rows 2, 3 of one patch are rows 0, 1 of the next: no copies).
+  float a01, a02, a11, a12, bx[8], by[8];
+  auto coltf = [&](float (&o)[8], int h, int r) {                 // o[4h ..] <- column transform of raw row r
+    o[4 * h + 0] = d[4 * r + 0] - d[4 * r + 2]; o[4 * h + 1] = d[4 * r + 1] + d[4 * r + 2];
+    o[4 * h + 2] = d[4 * r + 2] - d[4 * r + 1]; o[4 * h + 3] = d[4 * r + 1] - d[4 * r + 3];
+  };
+  auto xform = [&](int grp, int pr, float (&U)[16], float (&V)[16], bool count_bias) {
+    float (&up)[8] = (pr & 1) ? by : bx;                           // transformed rows 0, 1 of this patch
+    float (&lo)[8] = (pr & 1) ? bx : by;                           // rows 2, 3 (new)
+    if (grp == 0) { a01 = U[0] + U[3]; a02 = U[0] - U[3]; a11 = U[12] + U[15]; a12 = U[12] - U[15]; }
+    if (grp == 1) { U[4] = U[0] + U[12]; U[5] = a01 + a11; U[6] = a02 + a12; U[7] = U[3] + U[15]; }
     if (grp == 2) {
-      U[8] = g[0] - g[2]; U[9] = a01 - a11; U[10] = a02 - a12; U[11] = g[1] - g[3];
-      U[0] = g[0]; U[1] = a01; U[2] = a02; U[3] = g[1]; U[12] = g[2]; U[13] = a11; U[14] = a12; U[15] = g[3];
+      U[8] = U[0] - U[12]; U[9] = a01 - a11; U[10] = a02 - a12; U[11] = U[3] - U[15];
+      U[1] = a01; U[2] = a02; U[13] = a11; U[14] = a12;
       if (do_bias) bsum += count_bias ? a01 + a11 : 0.f;        // (the operands formed behind the last tile are not real)
     }
-    if (grp >= 3 && grp <= 6) {
-      const int r = grp - 3;
-      bq[4 * r + 0] = d[4 * r + 0] - d[4 * r + 2]; bq[4 * r + 1] = d[4 * r + 1] + d[4 * r + 2];
-      bq[4 * r + 2] = d[4 * r + 2] - d[4 * r + 1]; bq[4 * r + 3] = d[4 * r + 1] - d[4 * r + 3];
-    }
-    if (grp == 7) { for (int q = 0; q < 4; ++q) V[q] = bq[q] - bq[8 + q]; }
-    if (grp == 8) { for (int q = 0; q < 4; ++q) V[4 + q] = bq[4 + q] + bq[8 + q]; }
-    if (grp == 9) { for (int q = 0; q < 4; ++q) V[8 + q] = bq[8 + q] - bq[4 + q]; }
-    if (grp == 10) { for (int q = 0; q < 4; ++q) V[12 + q] = bq[4 + q] - bq[12 + q]; }
+    if (grp == 3 && pr == 0) coltf(up, 0, 0);
+    if (grp == 4 && pr == 0) coltf(up, 1, 1);
+    if (grp == 5) coltf(lo, 0, 2);
+    if (grp == 6) coltf(lo, 1, 3);
+    if (grp == 7) { for (int q = 0; q < 4; ++q) V[q] = up[q] - lo[q]; }
+    if (grp == 8) { for (int q = 0; q < 4; ++q) V[4 + q] = up[4 + q] + lo[q]; }
+    if (grp == 9) { for (int q = 0; q < 4; ++q) V[8 + q] = lo[q] - up[4 + q]; }
+    if (grp == 10) { for (int q = 0; q < 4; ++q) V[12 + q] = up[4 + q] - lo[4 + q]; }
   };
   // One k-step = 16 MFMAs on (U, V); in their shadow, by hand (one sched_barrier per MFMA): slots 0-4 the raw reads of the NEXT
-  // step (buffer nb, step nk), slots 5-15 its transform into (UN, VN); slots 7 and 15: one DMA piece each of tile `dt` into `db`
+  // step (buffer nb, step nk; rows 0, 1 of x only at the top of a column), slots 5-15 its transform into (UN, VN); slots 7 and
+  // 15: one DMA piece each (2 dj, 2 dj + 1) of the tile described by dc into buffer db
   auto kstep = [&](const float (&U)[16], const float (&V)[16], int nb, int nk, float (&UN)[16], float (&VN)[16],
                    const TileCtx& dc, int db, int dj, bool dlive, bool next_real) {
-    const float* ap = smem + nb * W22_TILE_FLOATS + aoff + ((2 * (nk >> 2)) * 16 + 4 * (nk & 3)) * 64;
-    const float* bp = smem + nb * W22_TILE_FLOATS + boff + ((2 * (nk >> 2)) * W22_IW + 4 * (nk & 3)) * 64;
+    const float *ap, *bp;
+    raw_ptrs(nb, nk, ap, bp);
+    const bool top = (nk & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[i], V[i], acc[i], 0, 0, 0);
-      if (i == 0) { g[0] = ap[0]; g[1] = ap[64]; g[2] = ap[16 * 64]; g[3] = ap[17 * 64]; }
-      if (i >= 1 && i <= 4) {
-        const int r = i - 1;
+#ifndef W22_NO_LDS
+      if (i == 0) { UN[0] = ap[0]; UN[3] = ap[64]; UN[12] = ap[16 * 64]; UN[15] = ap[17 * 64]; }
+      if (i == 1 || i == 2 || (top && (i == 3 || i == 4))) {
+        const int r = i <= 2 ? i + 1 : i - 3;                      // rows 2, 3 first, then (top) rows 0, 1
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
       }
-      if (i >= 5) xform(i - 5, UN, VN, next_real);
+#endif
+#ifndef W22_NO_XFORM
+      if (i >= 5) xform(i - 5, nk & 3, UN, VN, next_real);
+#endif
+#ifndef W22_NO_DMA
       if (dj >= 0 && i == 7) piece(dc, db, 2 * dj, dlive);
       if (dj >= 0 && i == 15) piece(dc, db, 2 * dj + 1, dlive);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -746,9 +768,17 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
       const TileCtx c1 = tile_ctx(t_begin + 1);
       piece(c1, 1, 0, true); piece(c1, 1, 1, true);
     }
-    ld_raw(0, 0);
+    {
+      const float *ap, *bp;
+      raw_ptrs(0, 0, ap, bp);
+      U0[0] = ap[0]; U0[3] = ap[64]; U0[12] = ap[16 * 64]; U0[15] = ap[17 * 64];
 #pragma unroll
-    for (int grp = 0; grp < 11; ++grp) xform(grp, U0, V0, true);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
+    }
+#pragma unroll
+    for (int grp = 0; grp < 11; ++grp) xform(grp, 0, U0, V0, true);
   }
   int b = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
