@@ -42,34 +42,10 @@ extern "C" int srk_debug_set_wstamps(void* p) {
 #define WST_END() do { } while (0)
 #endif
 
+#include "srk_wgrad_internal.h"
+using namespace srkw;
+
 namespace {
-
-constexpr int WTW = 16;
-constexpr int MAX_PROB = 8;
-constexpr int MAX_CHUNK = 64;
-
-template <int S> struct WGeo {
-  static constexpr int TH = (S == 1) ? 4 : 2;
-  static constexpr int TP = TH * WTW;              // pixels per tile
-  static constexpr int IH = (TH - 1) * S + 3;
-  static constexpr int IW = (WTW - 1) * S + 3;
-  static constexpr int NHP = IH * IW;
-};
-
-struct WProb {
-  const float* x; const float* dy; float* dw; float* db;
-  int x_ldc, x_coff, dy_ldc, dy_coff, Cin, Cout, accumulate;
-  float in_slope, scale;
-};
-
-struct WBatch {
-  int N, H, W, OH, OW;
-  int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode, wino;
-  WProb prob[MAX_PROB];
-  unsigned char c_prob[MAX_CHUNK], c_cy[MAX_CHUNK], c_cz[MAX_CHUNK];
-};
-
-constexpr size_t CHUNK_FLOATS = 9 * 64 * 64;
 
 // KSP ("k-split") > 1 is used when every problem of the launch has Cout <= 32 or Cin <= 32 (discriminator layers):
 // a chunk then has only 1 or 2 live 32x32 wave tiles, so instead of idling the other waves, KSP waves share one dW tile
@@ -78,7 +54,6 @@ constexpr size_t CHUNK_FLOATS = 9 * 64 * 64;
 //
 // VEC staging uses buffer loads (per-image resource, out-of-range lanes point past num_records and read 0): no
 // divergent branches, so the compiler keeps all loads of a tile in flight instead of waiting after each one.
-constexpr unsigned W_OOB = 0x80000000u;
 
 template <int S, int DYMODE, bool VEC, int KSP>
 __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch B, float* part, float* pbias) {
@@ -316,9 +291,6 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
 // 192 accumulator VGPRs leave no room for staging registers: tiles go global -> LDS by DMA (buffer_load ... lds, 16 B per
 // lane, zero fill through the buffer range check), double-buffered, one barrier per tile.  8 waves = 4 (cout, cin) 32x32
 // tiles x 2 pixel halves (summed through LDS at the end, fixed order).
-__device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
-}
 
 #ifndef WW_PRIO
 #define WW_PRIO 0
@@ -569,273 +541,6 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_f32_wino_kernel(const WBatch
       }
   }
   if (do_bias && ks == 0) {
-    const float tot = bsum + __shfl_xor(bsum, 32);
-    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 2-D Winograd weight gradient ("wino22"): the transposed F(2,3) algorithm in BOTH image directions.  A 2 x 2 patch of dy and
-// the 4 x 4 patch of x around it give the nine taps from 16 products instead of 36 (the 1-D kernel above: 24):
-//     U = A g A^T (4 x 4 from the 2 x 2 dy patch),  V = B^T d B (4 x 4 from the x patch),  M_pq += U_pq V_pq  over all patches,
-//     dW = G^T M G  once, at the end          (A, B, G: the 1-D matrices of the kernel above, applied along columns then rows)
-// i.e. 4/9 of the direct kernel's MFMAs (1-D: 2/3).  The MFMA K index runs over PATCHES.
-// Shape: like the wino42 conv kernel, ONE wave per SIMD: workgroup = 4 waves = one 64 x 64 (cout, cin) chunk, wave (wa, wb) =
-// one 32 x 32 tile x 16 positions = 16 accumulator tiles (all 256 AGPRs); the operands of a k-step (two patches) are formed in
-// registers from 4 + 16 raw LDS dwords per lane (44 VALU per 16 MFMAs), one step ahead, in the shadow of the MFMAs.  Pixel tiles
-// of 8 rows x 16 columns (+ halo) go global -> LDS by DMA, two buffers; the tile barrier sits in front of the LAST k-step, whose
-// shadow already prepares the first step of the next tile from the other buffer.
-constexpr int W22_TH = 8;
-constexpr int W22_TP = W22_TH * WTW;                       // 128 dy pixels
-constexpr int W22_IH = W22_TH + 2, W22_IW = WTW + 2;       // 10 x 18 halo
-constexpr int W22_NHP = W22_IH * W22_IW;                   // 180
-constexpr int W22_TILE_FLOATS = 80 * 256;                  // (128 + 180) pixels x 64 channels, padded to 80 DMA slots: 81,920 B per buffer
-constexpr int W22_THREADS = 256;
-
-template <int DYMODE>
-__global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBatch B, float* part, float* pbias) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 163,840 B: all of the LDS
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = lane >> 5, l32 = lane & 31;
-  const int wa = wv & 1, wb = wv >> 1;
-  int p, chunk;
-  {
-    const int id = blockIdx.x, nc = B.n_chunks, pm = B.P & ~7;      // XCD-aware placement, as in wgrad_f32_wino_kernel
-    if (id < pm * nc) { const int s_ = id >> 3; p = (id & 7) + 8 * (s_ / nc); chunk = s_ - (s_ / nc) * nc; }
-    else { const int r_ = id - pm * nc; p = pm + r_ / nc; chunk = r_ - (r_ / nc) * nc; }
-  }
-  const int pi = __builtin_amdgcn_readfirstlane(B.c_prob[chunk]);
-  const int cy = __builtin_amdgcn_readfirstlane(B.c_cy[chunk]), cz = __builtin_amdgcn_readfirstlane(B.c_cz[chunk]);
-  const WProb& a = B.prob[pi];
-  const int cin0 = cy * 64, cout0 = cz * 64;
-  const bool active = (cout0 + 32 * wa < a.Cout) && (cin0 + 32 * wb < a.Cin);
-  const bool do_bias = (a.db != nullptr) && cy == 0 && wb == 0 && (cout0 + 32 * wa < a.Cout);
-  const int Cps = a.Cout >> 2;
-
-  f32x16 acc[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
-
-  const int t_begin = p * B.tpb;
-  int t_end = t_begin + B.tpb;
-  if (t_end > B.total_tiles) t_end = B.total_tiles;
-
-  const long x_img = (long)B.H * B.W * a.x_ldc;
-  const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
-  const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
-  const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
-  const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
-  // ---- DMA plan.  A wave-wide instruction moves 4 consecutive pixels x 16 channel quads (1 KB, 8 cache lines): 32 of dy,
-  // 45 of x per tile, 80 slots (the tile buffer is padded to 80 KB so that all four waves own exactly 20: instruction 4 j + wv).
-  // Everything that depends on the lane is computed ONCE: the byte offset of the piece relative to the tile origin and its
-  // column relative to the tile origin.  Issuing a piece is then 6 instructions, none of them a branch (the k-steps stay ONE
-  // basic block, so the hand-placed order below survives): rows outside the image fall out of the per-image buffer range by
-  // themselves (negative offsets wrap), only the column needs a test.
-  constexpr int NDY = W22_TP * 16 / 64;                            // 32 dy instructions
-  constexpr int NINST = NDY + W22_NHP * 16 / 64;                   // 77 live instructions
-  constexpr int NPW = 20;
-  static_assert(NDY % 4 == 0 && NINST <= 4 * NPW && 4 * NPW * 256 <= W22_TILE_FLOATS, "DMA slots");
-  const int c4 = lane & 15, lp = lane >> 4;
-  const int co = cout0 + 4 * c4, ci = cin0 + 4 * c4;
-  int dyc, dyij = 0;
-  if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
-  const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
-  unsigned rel[NPW];
-  int colx[NPW];
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int i = 4 * j + wv;
-    if (j < NDY / 4) {
-      const int r = i >> 2, c = 4 * (i & 3) + lp;                  // pixel 4i + lp of the 8 x 16 tile
-      if (DYMODE == SRK_IN_UNSHUFFLE) rel[j] = (unsigned)((((2 * r + (dyij >> 1)) * (2 * B.OW) + 2 * c + (dyij & 1)) * a.dy_ldc + dyc) * 4);
-      else rel[j] = (unsigned)(((r * B.OW + c) * a.dy_ldc + dyc) * 4);
-      colx[j] = co_ok ? c : -(1 << 20);
-    } else {
-      const int hp = 4 * (i - NDY) + lp;                           // halo pixel 0..179 (beyond: the padding slots)
-      const int hy = hp / W22_IW, hx = hp - hy * W22_IW;
-      rel[j] = (unsigned)((((hy - 1) * B.W + (hx - 1)) * a.x_ldc + ci) * 4);
-      colx[j] = (ci_ok && i < NINST) ? hx - 1 : -(1 << 20);
-    }
-  }
-  struct TileCtx { int ow0; unsigned org_dy, org_x; __amdgpu_buffer_rsrc_t xr, dr; };
-  auto tile_ctx = [&](int tile) {
-    int tt = tile;
-    const int tx = tt % B.tilesW; tt /= B.tilesW;
-    const int ty = tt % B.tilesH; tt /= B.tilesH;
-    const int n = tt;
-    TileCtx c;
-    const int oh0 = ty * W22_TH;
-    c.ow0 = tx * WTW;
-    c.org_dy = (unsigned)((DYMODE == SRK_IN_UNSHUFFLE ? (2 * oh0 * 2 * B.OW + 2 * c.ow0) : (oh0 * B.OW + c.ow0)) * a.dy_ldc * 4);
-    c.org_x = (unsigned)((oh0 * B.W + c.ow0) * a.x_ldc * 4);
-    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
-    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
-    return c;
-  };
-  // piece j of this wave (j: compile-time after unrolling); `live` false (wave-uniform): issued out of range -- nothing is read,
-  // zeros land in a buffer nobody reads any more
-  auto piece = [&](const TileCtx& c, int b, int j, bool live) {
-    float* dst = smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256;
-    const bool isdy = j < NDY / 4;
-    const unsigned off = rel[j] + (isdy ? c.org_dy : c.org_x);
-    const bool ok = live && (unsigned)(colx[j] + c.ow0) < (unsigned)(isdy ? B.OW : B.W);
-    wdma16(isdy ? c.dr : c.xr, dst, ok ? off : W_OOB);
-  };
-
-  // per-lane LDS offsets (floats) of patch (row 0, columns 2 * 0 + hl)
-  const int aoff = (2 * hl) * 64 + 32 * wa + l32;                              // dy pixel (0, 2 hl)
-  const int boff = W22_TP * 64 + (2 * hl) * 64 + 32 * wb + l32;                // halo pixel (0, 2 hl)
-
-  // K-step order: DOWN the patch columns, kk = 4 * (column pair) + (patch row).  Vertically adjacent patches share two of their
-  // four x rows, so for patch rows 1-3 only the two new rows are read and column-transformed (12 instead of 20 LDS dwords, 36
-  // instead of 44 VALU per step); the transformed rows 2, 3 of the previous step are carried in registers as rows 0, 1.
-  float U0[16], V0[16], U1[16], V1[16], d[16];
-  auto raw_ptrs = [&](int bb, int kk, const float*& ap, const float*& bp) {
-    const int pr = kk & 3, cp = kk >> 2;
-    ap = smem + bb * W22_TILE_FLOATS + aoff + ((2 * pr) * 16 + 4 * cp) * 64;
-    bp = smem + bb * W22_TILE_FLOATS + boff + ((2 * pr) * W22_IW + 4 * cp) * 64;
-  };
-  // the VALU operations of the operand transform in groups of 4 (one group per MFMA slot).  The four dy values are loaded
-  // straight into U[0], U[3], U[12], U[15] (the corner positions ARE the raw values); the column-transformed x rows live in two
-  // register sets that swap roles from patch row to patch row (rows 2, 3 of one patch are rows 0, 1 of the next: no copies).
-  float a01, a02, a11, a12, bx[8], by[8];
-  auto coltf = [&](float (&o)[8], int h, int r) {                 // o[4h ..] <- column transform of raw row r
-    o[4 * h + 0] = d[4 * r + 0] - d[4 * r + 2]; o[4 * h + 1] = d[4 * r + 1] + d[4 * r + 2];
-    o[4 * h + 2] = d[4 * r + 2] - d[4 * r + 1]; o[4 * h + 3] = d[4 * r + 1] - d[4 * r + 3];
-  };
-  auto xform = [&](int grp, int pr, float (&U)[16], float (&V)[16], bool count_bias) {
-    float (&up)[8] = (pr & 1) ? by : bx;                           // transformed rows 0, 1 of this patch
-    float (&lo)[8] = (pr & 1) ? bx : by;                           // rows 2, 3 (new)
-    if (grp == 0) { a01 = U[0] + U[3]; a02 = U[0] - U[3]; a11 = U[12] + U[15]; a12 = U[12] - U[15]; }
-    if (grp == 1) { U[4] = U[0] + U[12]; U[5] = a01 + a11; U[6] = a02 + a12; U[7] = U[3] + U[15]; }
-    if (grp == 2) {
-      U[8] = U[0] - U[12]; U[9] = a01 - a11; U[10] = a02 - a12; U[11] = U[3] - U[15];
-      U[1] = a01; U[2] = a02; U[13] = a11; U[14] = a12;
-      if (do_bias) bsum += count_bias ? a01 + a11 : 0.f;        // (the operands formed behind the last tile are not real)
-    }
-    if (grp == 3 && pr == 0) coltf(up, 0, 0);
-    if (grp == 4 && pr == 0) coltf(up, 1, 1);
-    if (grp == 5) coltf(lo, 0, 2);
-    if (grp == 6) coltf(lo, 1, 3);
-    if (grp == 7) { for (int q = 0; q < 4; ++q) V[q] = up[q] - lo[q]; }
-    if (grp == 8) { for (int q = 0; q < 4; ++q) V[4 + q] = up[4 + q] + lo[q]; }
-    if (grp == 9) { for (int q = 0; q < 4; ++q) V[8 + q] = lo[q] - up[4 + q]; }
-    if (grp == 10) { for (int q = 0; q < 4; ++q) V[12 + q] = up[4 + q] - lo[4 + q]; }
-  };
-  // One k-step = 16 MFMAs on (U, V); in their shadow, by hand (one sched_barrier per MFMA): slots 0-4 the raw reads of the NEXT
-  // step (buffer nb, step nk; rows 0, 1 of x only at the top of a column), slots 5-15 its transform into (UN, VN); slots 7 and
-  // 15: one DMA piece each (2 dj, 2 dj + 1) of the tile described by dc into buffer db
-  auto kstep = [&](const float (&U)[16], const float (&V)[16], int nb, int nk, float (&UN)[16], float (&VN)[16],
-                   const TileCtx& dc, int db, int dj, bool dlive, bool next_real) {
-    const float *ap, *bp;
-    raw_ptrs(nb, nk, ap, bp);
-    const bool top = (nk & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[i], V[i], acc[i], 0, 0, 0);
-#ifndef W22_NO_LDS
-      if (i == 0) { UN[0] = ap[0]; UN[3] = ap[64]; UN[12] = ap[16 * 64]; UN[15] = ap[17 * 64]; }
-      if (i == 1 || i == 2 || (top && (i == 3 || i == 4))) {
-        const int r = i <= 2 ? i + 1 : i - 3;                      // rows 2, 3 first, then (top) rows 0, 1
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
-      }
-#endif
-#ifndef W22_NO_XFORM
-      if (i >= 5) xform(i - 5, nk & 3, UN, VN, next_real);
-#endif
-#ifndef W22_NO_DMA
-      if (dj >= 0 && i == 7) piece(dc, db, 2 * dj, dlive);
-      if (dj >= 0 && i == 15) piece(dc, db, 2 * dj + 1, dlive);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if (t_begin < t_end) {
-    const TileCtx c0 = tile_ctx(t_begin);
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) piece(c0, 0, j, true);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
-  __syncthreads();
-  if (t_begin < t_end) {
-    if (t_begin + 1 < t_end) {                                     // (the state every tile starts in: pieces 0, 1 of the next one issued)
-      const TileCtx c1 = tile_ctx(t_begin + 1);
-      piece(c1, 1, 0, true); piece(c1, 1, 1, true);
-    }
-    {
-      const float *ap, *bp;
-      raw_ptrs(0, 0, ap, bp);
-      U0[0] = ap[0]; U0[3] = ap[64]; U0[12] = ap[16 * 64]; U0[15] = ap[17 * 64];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
-    }
-#pragma unroll
-    for (int grp = 0; grp < 11; ++grp) xform(grp, 0, U0, V0, true);
-  }
-  int b = 0;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    // tile sits in buffer b, tile + 1 is in flight into b ^ 1 (issued during the previous tile); tile + 2 goes into b once the
-    // barrier in front of the last k-step has released it: its pieces ride on that step and on steps 0-8 of the next tile.
-    const bool more1 = tile + 1 < t_end;
-    const TileCtx cn = tile_ctx(more1 ? tile + 1 : tile);          // (the tile whose pieces 2-19 are issued during THIS tile's steps 0-8)
-    const bool livep = more1;
-    const int bnp = b ^ 1;
-#pragma unroll
-    for (int kk = 0; kk < 14; kk += 2) {
-      kstep(U0, V0, b, kk + 1, U1, V1, cn, bnp, kk < 9 ? kk + 1 : -1, livep, true);
-      kstep(U1, V1, b, kk + 2, U0, V0, cn, bnp, kk + 1 < 9 ? kk + 2 : -1, livep, true);
-    }
-    kstep(U0, V0, b, 15, U1, V1, cn, bnp, -1, false, true);        // k-step 14
-    __builtin_amdgcn_s_waitcnt(0x0070);                            // every piece of tile + 1 has landed (no other VMEM in flight)
-    __builtin_amdgcn_s_barrier();
-    {
-      const bool more2 = tile + 2 < t_end;
-      const TileCtx c2 = tile_ctx(more2 ? tile + 2 : tile);
-      kstep(U1, V1, bnp, 0, U0, V0, c2, b, 0, more2, more1);       // k-step 15: pieces 0, 1 of tile + 2; first operands of tile + 1
-    }
-    b ^= 1;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);
-  __syncthreads();
-
-  // G^T M G: taps from the 4 x 4 positions (columns q first, then rows p)
-  f32x16 tap[9];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float T[4][3];
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      const float m0 = acc[4 * pp][e], m1 = acc[4 * pp + 1][e], m2 = acc[4 * pp + 2][e], m3 = acc[4 * pp + 3][e];
-      const float hs = 0.5f * (m1 + m2);
-      T[pp][0] = m0 + hs; T[pp][1] = 0.5f * (m1 - m2); T[pp][2] = hs - m3;
-    }
-#pragma unroll
-    for (int sx = 0; sx < 3; ++sx) {
-      const float hs = 0.5f * (T[1][sx] + T[2][sx]);
-      tap[sx][e] = T[0][sx] + hs;
-      tap[3 + sx][e] = 0.5f * (T[1][sx] - T[2][sx]);
-      tap[6 + sx][e] = hs - T[3][sx];
-    }
-  }
-  if (active) {
-    float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
-        dst[(t * 64 + 32 * wa + i) * 64 + 32 * wb + l32] = tap[t][reg];
-      }
-  }
-  if (do_bias) {
     const float tot = bsum + __shfl_xor(bsum, 32);
     if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
@@ -1331,9 +1036,12 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     if (ks_env < 0) { const char* e = getenv("SRK_WGRAD_KSPLIT"); ks_env = e ? atoi(e) : 1; }
     if (!ks_env) ksp = 1;
   }
-  if (S == 1 && VEC && B.wino == 2)
-    hipLaunchKernelGGL((wgrad_f32_wino22_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(W22_THREADS), 0, st, B, part, pbias);
-  else if (S == 1 && VEC && B.wino)
+  if (S == 1 && VEC && B.wino == 2) {
+    const int rc = srk_launch_wgrad_wino22(B, part, pbias, st);
+    if (rc) return rc;
+    return launch_reduce(B, part, pbias, st);
+  }
+  if (S == 1 && VEC && B.wino)
     hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(WW_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 4)
     hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
