@@ -9,6 +9,57 @@ namespace {
 // work item = one float4 of dst: (q_local, tap, h, m) -> 4 consecutive k.
 // fmt 3 ("wino"): 12 taps = 3 kernel rows x 4 Winograd F(2,3) positions along the kernel's column axis,
 //   u0 = w0, u1 = (w0 + w1 + w2)/2, u2 = (w0 - w1 + w2)/2, u3 = w2   (w_s = the row's three column taps)
+// fmt 6 (F(2x4, 3x3)): work item = (m, h, row position rp, q_local) -> the six column positions of 4 consecutive k: the nine taps
+// of a channel pair are read once per row position instead of once per transformed tap.
+__device__ __forceinline__ void pack_item6(const srk_pack_entry& e, long t) {
+  const int Mp = (e.M + 31) & ~31;
+  const int m = (int)(t % Mp); t /= Mp;
+  const int h = (int)(t & 1); t >>= 1;
+  const int rp = (int)(t & 3); t >>= 2;
+  const int q = (e.k_off >> 3) + (int)t;
+  const int Cps = e.src_cout >> 2;
+  float v[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 8 * q + 4 * h + j, kr = k - e.k_off;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (m < e.M && kr >= 0 && kr < e.k_len) {
+      const float* w9;
+      if (!e.transpose) {
+        int o = m;
+        if (e.ps) o = 4 * (m % Cps) + m / Cps;
+        w9 = e.src + ((long)o * e.src_cin + e.c_begin + kr) * 9;
+      } else {
+        int o = kr;
+        if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
+        w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float c0, c1, c2;                       // column tap b of kernel rows 0, 1, 2 (data gradient: taps flipped)
+        if (!e.transpose) { c0 = w9[b]; c1 = w9[3 + b]; c2 = w9[6 + b]; }
+        else { c0 = w9[8 - b]; c1 = w9[5 - b]; c2 = w9[2 - b]; }
+        g[b] = e.scale * (rp == 0 ? c0 : rp == 1 ? 0.5f * ((c0 + c1) + c2) : rp == 2 ? 0.5f * ((c0 - c1) + c2) : c2);
+      }
+    }
+    const float w0 = g[0], w1 = g[1], w2 = g[2];
+    v[0][j] = 0.25f * w0;
+    v[1][j] = (-1.f / 6.f) * ((w0 + w1) + w2);
+    v[2][j] = (-1.f / 6.f) * ((w0 - w1) + w2);
+    v[3][j] = (w0 * (1.f / 24.f) + w1 * (1.f / 12.f)) + w2 * (1.f / 6.f);
+    v[4][j] = (w0 * (1.f / 24.f) - w1 * (1.f / 12.f)) + w2 * (1.f / 6.f);
+    v[5][j] = w2;
+  }
+  // [q][channel pair][tap = 6 rp + p][h][Mp] float2
+  float2* d2 = reinterpret_cast<float2*>(e.dst);
+#pragma unroll
+  for (int p6 = 0; p6 < 6; ++p6) {
+    const int tap = 6 * rp + p6;
+    d2[((((long)q * 2 + 0) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[p6][0], v[p6][1]);
+    d2[((((long)q * 2 + 1) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[p6][2], v[p6][3]);
+  }
+}
+
 __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
@@ -100,13 +151,13 @@ __global__ void pack_kernel(const srk_pack_entry* __restrict__ tab, int n, long 
     if (tab[mid].elem_begin <= gid) lo = mid; else hi = mid - 1;
   }
   const srk_pack_entry e = tab[lo];
-  pack_item(e, gid - e.elem_begin);
+  if (e.fmt == 6) pack_item6(e, gid - e.elem_begin); else pack_item(e, gid - e.elem_begin);
 }
 
 // one entry passed by value (the flat entry points below: no device-side table to upload)
 __global__ void pack_one_kernel(const srk_pack_entry e, long total) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < total) pack_item(e, gid);
+  if (gid < total) { if (e.fmt == 6) pack_item6(e, gid); else pack_item(e, gid); }
 }
 
 // bias[o] -> packed PixelShuffle order p = (2i+j)*Cout/4 + c  <-  o = 4c + 2i + j
@@ -240,7 +291,7 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
     int k_end = e[i].k_off + e[i].k_len;
     int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
     // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
-    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : (e[i].fmt == 6 ? 24 : 9))) * 2 * srk_round_up(e[i].M, 32);
+    acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : (e[i].fmt == 6 ? 4 : 9))) * 2 * srk_round_up(e[i].M, 32);   // (fmt 6: one item per row position)
   }
   *total = acc;
   return SRK_OK;
