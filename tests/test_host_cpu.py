@@ -310,3 +310,13 @@ def test_transposed_conv_variants_keep_the_reference_state_dict(srk, golden_dir)
         g2 = pickle.loads(pickle.dumps(g))
         assert list(g2.state_dict().keys()) == lines[tag].split() and g2._engine.gen is g2
     assert not srk.GeneratorRRDB(1, 16, 1).modulewise
+
+
+def test_inline_asm_mfma_hazards_of_the_wino42_kernel():
+    """The F(2x4,3x3) conv kernel issues its MFMAs as inline assembly (register classes spelled out), which the compiler's
+    hazard recogniser does not see: the generated code must keep two wait states between a VALU write and an MFMA read."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_w42_hazards.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 hazard(s)" in r.stdout
