@@ -128,6 +128,9 @@ int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_
 /* Test aid: routing of convolutions with <= 4 channels on one side to the HBM-bound kernels of srk_conv_small.hip:
  * 0 = never, 1 = when their 16x16 tiles fill the chip (default), 2 = whenever the shape allows (small parity cases). */
 int srk_debug_set_conv_small(int mode);
+/* Test aid: M tiles per workgroup of the F(2x4, 3x3) conv kernel (wp_format 6): 0 = by launch size (default), 1 = 16-row tiles,
+ * 2 = 32-row tiles. */
+int srk_debug_set_wino42_nmt(int nmt);
 /* Measurement aid: writes the name (as rocprofv3 prints it) of the kernel srk_conv3x3 dispatches to for these arguments into
  * buf (NUL-terminated, truncated to len).  Launches nothing. */
 int srk_conv3x3_kernel_name(const srk_conv_args* args, char* buf, size_t len);

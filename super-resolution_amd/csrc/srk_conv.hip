@@ -1079,6 +1079,7 @@ int launch_bn(const srk_conv_args& a, hipStream_t st) {
 
 int srk_launch_conv_bf16x3(const srk_conv_args& a, hipStream_t st);
 int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st);      // srk_conv_w42.hip
+int srk_conv_wino42_nmt(const srk_conv_args& a);
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1169,7 +1170,7 @@ extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_
     snprintf(buf, len, g_wino4_nh == 1 ? "conv3x3_f32_wino4h_kernel<%d>" : "conv3x3_f32_wino4_kernel<%d>", a.in_mode);
     return SRK_OK;
   }
-  if (a.wp_format == 6) { snprintf(buf, len, "conv3x3_f32_wino42_kernel<%d>", a.in_mode); return SRK_OK; }
+  if (a.wp_format == 6) { snprintf(buf, len, "conv3x3_f32_wino42_kernel<%d, %d>", a.in_mode, srk_conv_wino42_nmt(a)); return SRK_OK; }
   if (a.wp_format == 3) { snprintf(buf, len, "conv3x3_f32_wino_kernel<%d>", a.in_mode); return SRK_OK; }
   if (a.wp_format != 0) return SRK_ERR_UNSUPPORTED;
   if (const int small = srk_conv_small_kind(a)) {

@@ -47,11 +47,16 @@ __device__ unsigned long long* g_w42_stamps = nullptr;
 // A lane reads, for its patch (row pair k, column quad t), pixels (2k + d, 4t + j): slot = 37 k + 4 t + const, and the M-tile
 // map below makes 37 k + 4 t distinct mod 16 over every 16-lane group of a ds_read_b128 and 2-uniform over the 32-lane groups
 // of a ds_read_b64 (the minimum) -- conflict-free reads although patches step by two rows and four pixels.
-template <int MODE>
+// NMT = M tiles per workgroup: 2 = the 32 x 16-pixel form described above; 1 = a 16 x 16-pixel form (12 accumulator tiles per wave,
+// half the MFMAs per weight load and per barrier) for launches whose 32-row tiles would leave CUs idle (batch 16 at 64 x 64).
+template <int MODE, int NMT>
 __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
-  constexpr int TH = 32, IH = TH + 2, IW = SRK_TW + 2;
-  constexpr int HS4 = 640, BUF4 = 2 * HS4;          // 1280 float4 = 20 KB per chunk = 20 DMA instructions of 1 KB
-  constexpr int SMEM4 = 9216;                       // 144 KB: max(2 halo buffers, 128 KB of exchange + 4 x 4 KB epilogue scratch)
+  constexpr int TH = 16 * NMT, IH = TH + 2, IW = SRK_TW + 2;
+  constexpr int HS4 = NMT == 2 ? 640 : 384;         // slots per k-half: 37 per row pair (17 resp. 9 pairs), padded to whole instructions
+  constexpr int BUF4 = 2 * HS4;                     // 1280 float4 = 20 KB (NMT 2) / 768 = 12 KB (NMT 1) per chunk
+  constexpr int NPC = BUF4 / 256;                   // DMA pieces per wave and chunk: 5 / 3
+  constexpr int EXSLOTS = 16 * NMT;                 // 4 KB slots of the exchange area (64 KB per M tile)
+  constexpr int SMEM4 = (EXSLOTS + 4) * 256;        // 144 KB / 80 KB: exchange + 4 x 4 KB epilogue scratch (>= 2 halo buffers)
   __shared__ float4 smem[SMEM4];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -81,11 +86,11 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const unsigned wbytes = (unsigned)((long)nq * 96 * CoutP * 8);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
-  unsigned vo[5];
+  unsigned vo[NPC];
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NPC; ++j) {
       const int slot = (wv + 4 * j) * 64 + lane;
       const int half = slot >= HS4 ? 1 : 0, p = slot - half * HS4;
       const int R = p / 37, rem = p - R * 37;
@@ -131,7 +136,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const unsigned sB_c = (unsigned)(2 * CoutP * 8);              // one column position
   const unsigned sB_ep = 24u * sB_c;                            // one channel pair of the chunk's k-halves
 
-  f32x16 acc[24];
+  f32x16 acc[12 * NMT];
   auto mfma = [&](int t, float va, float vb) {       // t is a constant after unrolling: one of the two statements survives
     // HAZARD: a VALU result needs two wait states before an MFMA may read it, and the compiler's hazard recogniser does not look
     // into inline assembly.  The schedule below forms every operand at least one MFMA slot ahead of its use and the main loop is
@@ -171,7 +176,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int c = i >> 1, nh = i & 1;
-      mfma((2 * MT + nh) * 6 + c, V[c], B[c][nh][E]);
+      mfma((NMT * nh + MT) * 6 + c, V[c], B[c][nh][E]);
 #ifndef W42_NO_LB
       if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
 #endif
@@ -201,6 +206,16 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   auto chunk = [&](int q, auto bc) {
     constexpr int b = decltype(bc)::value;
     using Bc = std::integral_constant<int, b>; using Bn = std::integral_constant<int, b ^ 1>;
+    if constexpr (NMT == 1) {
+      // one M tile: (e) = (0) (1) | (2) | barrier | (3); pieces 1, 2 of chunk q + 1 behind (0), (1); piece 0 of chunk q + 2 behind (3)
+      phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
+      phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
+      phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      __syncthreads();
+      phase(I0{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
+      return;
+    }
     phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
     W42_SEG(0);
     phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I1{}, I0{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
@@ -223,7 +238,8 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     W42_SEG(8);
   };
 
-  piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{}); piece(0, 0, I3{}); piece(0, 0, I4{});
+  piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{});
+  if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
   {
     const unsigned so = (unsigned)wv * 6u * sB_c;
 #pragma unroll
@@ -275,16 +291,16 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   // (k = 8 mt + q + 4 (s >> 1), t = hb + 2 (s & 1)).  Column transform in registers (6 -> 4), then the four row positions are
   // combined through LDS: wave f collects registers 4 f .. 4 f + 3 of every wave, which are exactly the rows 8 m + 2 f, + 1
   // (m = 2 mt + (s >> 1)) of conv_epilogue's wave f.  Two passes (one per channel half): 128 KB of LDS each.
-  f32x16 out[4][2];
+  f32x16 out[2 * NMT][2];
   f32x4* ex = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[(2 * mt + nh) * 6 + 0][r], m1 = acc[(2 * mt + nh) * 6 + 1][r], m2 = acc[(2 * mt + nh) * 6 + 2][r], m3 = acc[(2 * mt + nh) * 6 + 3][r],
-                    m4 = acc[(2 * mt + nh) * 6 + 4][r], m5 = acc[(2 * mt + nh) * 6 + 5][r];
+        const int t0 = (NMT * nh + mt) * 6;
+        const float m0 = acc[t0 + 0][r], m1 = acc[t0 + 1][r], m2 = acc[t0 + 2][r], m3 = acc[t0 + 3][r], m4 = acc[t0 + 4][r], m5 = acc[t0 + 5][r];
         const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
         f32x4 z;
         z[0] = (m0 + s12) + s34;
@@ -292,15 +308,15 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
         z[2] = s12 + 4.f * s34;
         z[3] = (d12 + 8.f * d34) + m5;
         const int f = r >> 2, s = r & 3;
-        ex[(((wv * 4 + f) * 2 + mt) * 4 + s) * 64 + lane] = z;
+        ex[(((wv * 4 + f) * NMT + mt) * 4 + s) * 64 + lane] = z;
       }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f32x4 z0 = ex[(((0 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane], z1 = ex[(((1 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane];
-        const f32x4 z2 = ex[(((2 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane], z3 = ex[(((3 * 4 + wv) * 2 + mt) * 4 + s) * 64 + lane];
+        const f32x4 z0 = ex[(((0 * 4 + wv) * NMT + mt) * 4 + s) * 64 + lane], z1 = ex[(((1 * 4 + wv) * NMT + mt) * 4 + s) * 64 + lane];
+        const f32x4 z2 = ex[(((2 * 4 + wv) * NMT + mt) * 4 + s) * 64 + lane], z3 = ex[(((3 * 4 + wv) * NMT + mt) * 4 + s) * 64 + lane];
         const f32x4 y0 = (z0 + z1) + z2, y1 = (z1 - z2) - z3;
         const int m = 2 * mt + (s >> 1), sx = s & 1;
 #pragma unroll
@@ -313,20 +329,40 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
-  conv_epilogue<64, 4, false, 16>(a, out, smem, n, oh0, ow0, n0, wv, lane, 32 + wv);
+  conv_epilogue<64, 2 * NMT, false, 16>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);
   W42_STAMP(5);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_args a) { wino42_body<MODE>(a); }
+template <int MODE, int NMT>
+__global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_args a) { wino42_body<MODE, NMT>(a); }
 
 }  // namespace
 
+// M tiles per workgroup: the 32-row form when its workgroups fill the chip (>= 200) and pad the image no more than 16-row tiles
+// would, else the 16-row form.  SRK_WINO42_NMT = 1 | 2 / srk_debug_set_wino42_nmt force one (A/B measurements, tests).
+static int g_w42_nmt = -1;
+extern "C" int srk_debug_set_wino42_nmt(int nmt) { g_w42_nmt = (nmt == 1 || nmt == 2) ? nmt : 0; return SRK_OK; }
+
+int srk_conv_wino42_nmt(const srk_conv_args& a) {
+  if (g_w42_nmt < 0) { const char* e = getenv("SRK_WINO42_NMT"); g_w42_nmt = e ? atoi(e) : 0; }
+  if (g_w42_nmt == 1 || g_w42_nmt == 2) return g_w42_nmt;
+  const int tilesW = srk_div_up(a.OW, SRK_TW), cb = srk_round_up(a.Cout, 64) / 64;
+  const bool fills = (long)a.N * srk_div_up(a.OH, 32) * tilesW * cb >= 200;
+  const bool tall = srk_round_up(a.OH, 32) == srk_round_up(a.OH, 16);
+  return (fills && tall) ? 2 : 1;
+}
+
 int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st) {
-  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, 32);
+  const int nmt = srk_conv_wino42_nmt(a);
+  const int tilesW = srk_div_up(a.OW, SRK_TW), tilesH = srk_div_up(a.OH, 16 * nmt);
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
-  if (a.in_mode == SRK_IN_PLAIN) hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_PLAIN>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_UNSHUFFLE>), grid, dim3(256), 0, st, a);
+  if (nmt == 2) {
+    if (a.in_mode == SRK_IN_PLAIN) hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_PLAIN, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_UNSHUFFLE, 2>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.in_mode == SRK_IN_PLAIN) hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_PLAIN, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_f32_wino42_kernel<SRK_IN_UNSHUFFLE, 1>), grid, dim3(256), 0, st, a);
+  }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }

@@ -275,7 +275,10 @@ class GeneratorEngine:
         image no more than the 16-row tiles of the F(2,3) kernel would."""
         gN, gH, gW = geo
         h, w = gH * up, gW * up
-        return gN * ((h + 31) // 32) * ((w + 15) // 16) * mtiles >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16
+        if gN * ((h + 31) // 32) * ((w + 15) // 16) * mtiles >= 200 and ((h + 31) // 32) * 32 == ((h + 15) // 16) * 16:
+            return True
+        # the F(2x4,3x3) kernel also has a 16-row-tile form (picked by its launcher): enough when THOSE tiles fill the chip
+        return os.environ.get("SRK_WINOGRAD42", "1") != "0" and gN * ((h + 15) // 16) * ((w + 15) // 16) * mtiles >= 200
 
     def _wino4_levels(self, geo, mtiles=1):
         """which resolution levels (1x, 2x, ... of the LR extent) run the F(4,3) kernel for a conv with `mtiles` output tiles"""

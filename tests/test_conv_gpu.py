@@ -476,12 +476,26 @@ def test_flat_workspace_and_errors(U):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Winograd F(2,3)-along-W kernel (wp_format 3): same fused conv, 2/3 of the MFMAs; fp32 throughout
+# Winograd kernels: wp_format 3 = F(2,3) along W (2/3 of the MFMAs), 5 = F(4,3) along W (1/2), 6 = 2-D F(2x4,3x3) (1/3; "62" below =
+# the same format with 32-row workgroup tiles forced, 6 = 16-row tiles forced: both forms of the kernel on every shape); fp32 throughout
+@pytest.fixture(autouse=True)
+def _reset_w42_form(U):
+    yield
+    U.L.lib().srk_debug_set_wino42_nmt(0)
+
+
+def _w42_form(U, fmt):
+    """test parameter -> wp_format, selecting the workgroup-tile form of the wino42 kernel"""
+    U.L.lib().srk_debug_set_wino42_nmt(2 if fmt == 62 else (1 if fmt == 6 else 0))
+    return 6 if fmt == 62 else fmt
+
+
 @pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 64, 64, 2), (320, 64, 16, 16, 1), (8, 64, 9, 7, 2), (64, 128, 33, 17, 1),
                                          (128, 64, 20, 40, 1), (16, 64, 5, 3, 1), (64, 64, 1, 1, 1), (24, 192, 16, 31, 2)])
-@pytest.mark.parametrize("fmt", [3, 5, 6])
+@pytest.mark.parametrize("fmt", [3, 5, 6, 62])
 def test_wino_conv_fwd(U, ci, co, h, w, n, fmt):
     L = U.L
+    fmt = _w42_form(U, fmt)
     x = _rand((n, ci, h, w), 71)
     wt = _rand((co, ci, 3, 3), 72, 1.0 / np.sqrt(9 * ci))
     b = _rand((co,), 73, 0.1)
@@ -492,8 +506,9 @@ def test_wino_conv_fwd(U, ci, co, h, w, n, fmt):
     assert U.rel_err(U.nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("fmt", [3, 5, 6])
+@pytest.mark.parametrize("fmt", [3, 5, 6, 62])
 def test_wino_slices_residuals_mask_and_dgrad(U, fmt):
+    fmt = _w42_form(U, fmt)
     """the dense-block addressing (channel prefix in, channel slice out, two residuals, alpha, LeakyReLU' mask) and the
     data gradient (transposed, tap-flipped weights through the same transform) on the Winograd kernel."""
     L = U.L
@@ -523,8 +538,9 @@ def test_wino_slices_residuals_mask_and_dgrad(U, fmt):
     assert U.rel_err(U.nchw(dx), x.grad) < TOL
 
 
-@pytest.mark.parametrize("fmt", [3, 5, 6])
+@pytest.mark.parametrize("fmt", [3, 5, 6, 62])
 def test_wino_pixel_shuffle_fold_and_unshuffle(U, fmt):
+    fmt = _w42_form(U, fmt)
     L = U.L
     n, F_, h, w = 2, 64, 8, 12
     x = _rand((n, F_, h, w), 83).requires_grad_(True)
