@@ -64,8 +64,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float4* lds_d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
+// (32-channel output tiles -- the discriminator layers -- are HBM-latency-bound with 2-4 K chunks of work per workgroup: ask for
+// four waves per SIMD (<= 128 registers) instead of the two the epilogue's prefetch depth would otherwise cost)
+#ifndef SRK_CONV_BN32_WAVES
+#define SRK_CONV_BN32_WAVES 4
+#endif
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
-__global__ __launch_bounds__(SRK_THREADS) void conv3x3_f32_kernel(const srk_conv_args a) {
+__global__ __launch_bounds__(SRK_THREADS, (BN == 32 ? SRK_CONV_BN32_WAVES : 1)) void conv3x3_f32_kernel(const srk_conv_args a) {
   using G = Geo<S, MT>;
   constexpr int NW4 = 18 * BN;                                  // weight float4 per chunk
   constexpr int NWS = (NW4 + SRK_THREADS - 1) / SRK_THREADS;
