@@ -70,7 +70,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float4* lds_d
 #define SRK_CONV_BN32_WAVES 4
 #endif
 template <int BN, int S, int MODE, bool VEC, int MT, bool DMA>
-__global__ __launch_bounds__(SRK_THREADS, (BN == 32 ? SRK_CONV_BN32_WAVES : 1)) void conv3x3_f32_kernel(const srk_conv_args a) {
+__global__ __launch_bounds__(SRK_THREADS, ((BN == 32 && S == 1) ? SRK_CONV_BN32_WAVES : 1)) void conv3x3_f32_kernel(const srk_conv_args a) {
   using G = Geo<S, MT>;
   constexpr int NW4 = 18 * BN;                                  // weight float4 per chunk
   constexpr int NWS = (NW4 + SRK_THREADS - 1) / SRK_THREADS;
