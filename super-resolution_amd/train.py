@@ -13,7 +13,9 @@ image of the pixel loss, the d_threshold decision) are exchanged too, so N ranks
 single-process step on N*B images.
 """
 import math
+import os
 
+import contextlib
 import torch
 import torch.nn as nn
 
@@ -92,6 +94,13 @@ class Stepper:
         if distributed and not self.generator.modulewise:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         self.last = {}
+        # the two discriminators of the D phase run on two streams (133.4 vs 135.3 ms per iteration); SRK_D_STREAMS=0: one stream.
+        # Single-process runs only: under data parallelism the D losses exchange batch statistics INSIDE their forward / backward
+        # (exact_dp), and collectives issued from side streams gained nothing with RCCL (1 rank: 136.1 vs 136.5 ms) and were
+        # pathologically slow in the two-ranks-on-one-GPU gloo rehearsal.
+        self._d_streams = None
+        if os.environ.get("SRK_D_STREAMS", "1") == "1" and not distributed and torch.cuda.is_available() and len(self.discriminators) == 2:
+            self._d_streams = {k: torch.cuda.Stream() for k in self.discriminators}
 
     # ------------------------------------------------------------------ helpers
     def set_hist_binedges(self, k, binedges):
@@ -273,12 +282,27 @@ class Stepper:
         loss_D_tot = {}
         nan_probe = None
         self.last_gate = {}
-        for k, D in (self.discriminators.items() if update_d else ()):
-            self.optimizer_D[k].zero_grad(set_to_none=True)
-            loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
-                                           cond=ground_truth_lr[k])
-            loss_D.backward()
-            self._sync_grads(D)
+        # The two discriminators are independent until their gradient exchange / gates: each runs its forward / loss / backward on
+        # its own stream -- their layers are short, latency-bound launches --, joined before anything is exchanged or read.
+        d_items = list(self.discriminators.items()) if update_d else []
+        two_streams = self._d_streams is not None and len(d_items) == 2
+        main = torch.cuda.current_stream() if two_streams else None
+        losses_D = {}
+        for k, D in d_items:
+            if two_streams:
+                self._d_streams[k].wait_stream(main)
+            with (torch.cuda.stream(self._d_streams[k]) if two_streams else contextlib.nullcontext()):
+                self.optimizer_D[k].zero_grad(set_to_none=True)
+                loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
+                                               cond=ground_truth_lr[k])
+                loss_D.backward()
+                losses_D[k] = loss_D
+        if two_streams:
+            for k, _ in d_items:
+                main.wait_stream(self._d_streams[k])
+        for k, D in d_items:
+            loss_D = losses_D[k]
+            self._sync_grads(D)          # (collectives stay on the main stream, in the same order on every rank)
             gate = loss_D.detach().reshape(1)
             if self.distributed:
                 # Every rank must take the same branch, or the replicas' weights and Adam states drift apart: the
