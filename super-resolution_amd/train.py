@@ -177,56 +177,70 @@ class Stepper:
         ground_truth_lr = [imgs_lr, imgs_lr ** p]
         loss_G = torch.zeros(1, device=imgs_lr.device)
         parts = {}
+        # (single-process runs: the two views' discriminator passes and losses on two streams, as in the D phase; autograd runs
+        # each view's backward on the stream of its forward)
+        two_streams = self._d_streams is not None and all(self.lambdas[k] > 0 for k in range(2))
+        main = torch.cuda.current_stream() if two_streams else None
+        tots = {}
         for k in range(2):
             if self.lambdas[k] <= 0:
                 continue
             D = self.discriminators[k]
-            loss_pixel = self.criterion_pixel(self._gmean(generated[k].mean(0))[None, ...], self._gmean(ground_truth[k].mean(0))[None, ...])
-            loss_lr_pixel = self.criterion_pixel(generated_lr[k], ground_truth_lr[k])
-            # gradients deposited on D's weights here are discarded by optimizer_D.zero_grad() (esrgan.py:568):
-            # do not compute them
-            for q in D.parameters():
-                q.requires_grad_(False)
-            with torch.no_grad():
-                pred_real = D(ground_truth[k], ground_truth_lr[k])
-            pred_fake = D(generated[k], generated_lr[k])
-            for q in D.parameters():
-                q.requires_grad_(True)
-            valid = torch.ones_like(pred_real)
-            fake = torch.zeros_like(pred_real)
-            if self.relativistic:      # esrgan.py:498-508
-                loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
-                                 self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
-            else:                      # esrgan.py:509-510
-                loss_GAN = self.criterion_GAN(EPS + pred_fake, valid)
-            tot = self.lambda_hr * loss_pixel + self.lambda_adv * loss_GAN + self.lambda_lr * loss_lr_pixel
-            parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach())
-            # optional physics heads: one fused HIP pass each (csrc/srk_loss.hip) instead of 3-6 HR-sized ATen ops.
-            # Under data parallelism these are per-rank means of per-rank batches (like the reference under DDP would be).
-            if self.lambda_nnz > 0:                                                    # esrgan.py:522-525
-                loss_nnz = self.mse(losses.soft_count(generated[k], 0.0, 50000.0), losses.hard_count(ground_truth[k], 0.0))
-                tot = tot + self.lambda_nnz * loss_nnz
-                parts[k]["nnz"] = loss_nnz.detach()
-            if self.lambda_mask > 0:                                                   # esrgan.py:526-529
-                loss_mask = losses.mask_l1(generated[k], ground_truth[k])
-                tot = tot + self.lambda_mask * loss_mask
-                parts[k]["mask"] = loss_mask.detach()
-            if self.lambda_hist > 0:                                                   # esrgan.py:530-538
-                if k not in self.histograms:
-                    raise RuntimeError("lambda_hist > 0 needs set_hist_binedges(k, edges) first (esrgan.py:441-456)")
-                gen_hist = self.histograms[k].forward_positive(generated[k])
-                real_hist = self.histograms[k].forward_positive(ground_truth[k])
-                loss_hist = self.criterion_hist[k](gen_hist, real_hist)
-                tot = tot + self.lambda_hist * loss_hist
-                parts[k]["hist"] = loss_hist.detach()
-            if self.lambda_hit > 0:                                                    # esrgan.py:543-547
-                gen_hit = losses.get_hitogram(generated[k], self.factor, self.hit_threshold, self.sigma)
-                target = losses.get_hitogram(ground_truth[k], self.factor, self.hit_threshold, self.sigma)
-                loss_hit = self.mse(gen_hit, target)
-                tot = tot + self.lambda_hit * loss_hit
-                parts[k]["hit"] = loss_hit.detach()
-            loss_G = loss_G + self.lambdas[k] * tot
-            parts[k]["tot"] = tot.detach()
+            if two_streams:
+                self._d_streams[k].wait_stream(main)
+            ctx = torch.cuda.stream(self._d_streams[k]) if two_streams else contextlib.nullcontext()
+            with ctx:
+                loss_pixel = self.criterion_pixel(self._gmean(generated[k].mean(0))[None, ...], self._gmean(ground_truth[k].mean(0))[None, ...])
+                loss_lr_pixel = self.criterion_pixel(generated_lr[k], ground_truth_lr[k])
+                # gradients deposited on D's weights here are discarded by optimizer_D.zero_grad() (esrgan.py:568):
+                # do not compute them
+                for q in D.parameters():
+                    q.requires_grad_(False)
+                with torch.no_grad():
+                    pred_real = D(ground_truth[k], ground_truth_lr[k])
+                pred_fake = D(generated[k], generated_lr[k])
+                for q in D.parameters():
+                    q.requires_grad_(True)
+                valid = torch.ones_like(pred_real)
+                fake = torch.zeros_like(pred_real)
+                if self.relativistic:      # esrgan.py:498-508
+                    loss_GAN = .5 * (self.criterion_GAN(EPS + pred_fake - self._gmean(pred_real.mean(0, keepdim=True)), valid) +
+                                     self.criterion_GAN(EPS + pred_real - self._gmean(pred_fake.mean(0, keepdim=True)), fake))
+                else:                      # esrgan.py:509-510
+                    loss_GAN = self.criterion_GAN(EPS + pred_fake, valid)
+                tot = self.lambda_hr * loss_pixel + self.lambda_adv * loss_GAN + self.lambda_lr * loss_lr_pixel
+                parts[k] = dict(pixel=loss_pixel.detach(), lr=loss_lr_pixel.detach(), adv=loss_GAN.detach())
+                # optional physics heads: one fused HIP pass each (csrc/srk_loss.hip) instead of 3-6 HR-sized ATen ops.
+                # Under data parallelism these are per-rank means of per-rank batches (like the reference under DDP would be).
+                if self.lambda_nnz > 0:                                                    # esrgan.py:522-525
+                    loss_nnz = self.mse(losses.soft_count(generated[k], 0.0, 50000.0), losses.hard_count(ground_truth[k], 0.0))
+                    tot = tot + self.lambda_nnz * loss_nnz
+                    parts[k]["nnz"] = loss_nnz.detach()
+                if self.lambda_mask > 0:                                                   # esrgan.py:526-529
+                    loss_mask = losses.mask_l1(generated[k], ground_truth[k])
+                    tot = tot + self.lambda_mask * loss_mask
+                    parts[k]["mask"] = loss_mask.detach()
+                if self.lambda_hist > 0:                                                   # esrgan.py:530-538
+                    if k not in self.histograms:
+                        raise RuntimeError("lambda_hist > 0 needs set_hist_binedges(k, edges) first (esrgan.py:441-456)")
+                    gen_hist = self.histograms[k].forward_positive(generated[k])
+                    real_hist = self.histograms[k].forward_positive(ground_truth[k])
+                    loss_hist = self.criterion_hist[k](gen_hist, real_hist)
+                    tot = tot + self.lambda_hist * loss_hist
+                    parts[k]["hist"] = loss_hist.detach()
+                if self.lambda_hit > 0:                                                    # esrgan.py:543-547
+                    gen_hit = losses.get_hitogram(generated[k], self.factor, self.hit_threshold, self.sigma)
+                    target = losses.get_hitogram(ground_truth[k], self.factor, self.hit_threshold, self.sigma)
+                    loss_hit = self.mse(gen_hit, target)
+                    tot = tot + self.lambda_hit * loss_hit
+                    parts[k]["hit"] = loss_hit.detach()
+                parts[k]["tot"] = tot.detach()
+                tots[k] = tot
+        if two_streams:
+            for k in tots:
+                main.wait_stream(self._d_streams[k])
+        for k in sorted(tots):
+            loss_G = loss_G + self.lambdas[k] * tots[k]
         return loss_G, generated, ground_truth, parts
 
     def d_phase_loss(self, k, gt, gen_detached, epsilon=None, cond=None):
