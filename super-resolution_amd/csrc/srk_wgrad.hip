@@ -962,7 +962,9 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   B.tilesH = srk_div_up(a0.OH, TH);
   B.total_tiles = a0.N * B.tilesH * B.tilesW;
   int target = (nc <= 2 ? small_target : 512) / nc;
-  if (B.wino) target = 256 / nc;
+  static int wino_target = -1;        // workgroups of a Winograd launch (A/B: finer splits interleave better with the conv chain when the launch runs beside it)
+  if (wino_target < 0) { const char* e = getenv("SRK_WGRAD_WINO_TARGET"); wino_target = e ? atoi(e) : 256; }
+  if (B.wino) target = wino_target / nc;
   if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
