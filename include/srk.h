@@ -144,6 +144,10 @@ int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, char* buf, 
  *       = scale * SRC(m, k = 8q + 4h + e, tap)      (0 where k >= K or m >= M)
  * forward entry  (transpose == 0): SRC(m,k,tap) = W[m'][c_begin + k - k_off][tap]
  * backward entry (transpose == 1): SRC(m,k,tap) = W[k' ][c_begin + m][8 - tap], k' from k - k_off
+ * stride-2 data gradient (transpose == 2; M = 4 * Cin): the data gradient of a STRIDE-2 conv written as a stride-1 conv on dy whose
+ *   4 x Cin outputs are PixelShuffled into dx (srk_conv3x3 with ps_out; even H, W): output m = (2a + b) * Cin + c is dx channel c at
+ *   pixel parity (a, b), SRC(m,k,3u+v) = W[k][c_begin + c][r(a,u)][s(b,v)] with r(0,1) = 1, r(1,1) = 2, r(1,2) = 0, else no tap (0):
+ *   a quarter of the multiply-adds of the zero-upsample form, and no 16 -> 32 channel padding
  * where x' = ps ? 4*(x % (Cout_src/4)) + x / (Cout_src/4) : x maps packed PixelShuffle order to OIHW rows.
  * Several entries may fill disjoint k ranges [k_off, k_off + k_len) of one dst (the backward of a
  * DenseResidualBlock reads the concatenation of dy5..dy(j+1)). */

@@ -9,6 +9,46 @@ namespace {
 // work item = one float4 of dst: (q_local, tap, h, m) -> 4 consecutive k.
 // fmt 3 ("wino"): 12 taps = 3 kernel rows x 4 Winograd F(2,3) positions along the kernel's column axis,
 //   u0 = w0, u1 = (w0 + w1 + w2)/2, u2 = (w0 - w1 + w2)/2, u3 = w2   (w_s = the row's three column taps)
+// The nine taps of (dst output m, dst input k = k_off + kr) in CONV-WINDOW order (w[3u + v] multiplies the input pixel at offset
+// (u - 1, v - 1) of the output pixel), for the three kinds of entry:
+//   transpose 0 (forward)        W[m'][c_begin + kr][u][v]
+//   transpose 1 (data gradient)  W[kr'][c_begin + m][2 - u][2 - v]                  (input / output swapped, taps flipped)
+//   transpose 2 (data gradient of a STRIDE-2 conv as a stride-1 conv on dy whose 4 x Cin outputs are PixelShuffled into dx:
+//                output m = (2a + b) Cin + c is dx channel c at pixel parity (a, b); dx[2i+a][2j+b] only sees dy[i + di][j + dj] with
+//                di, dj in {0, 1}: a = 0 -> kernel row 1 at di = 0; a = 1 -> row 2 at di = 0 and row 0 at di = 1; same for columns)
+//                W[kr][c_begin + c][r(a, u)][s(b, v)]  or 0 where the window position carries no tap
+// x' = ps ? 4 (x % (Cout_src / 4)) + x / (Cout_src / 4) : x  maps packed PixelShuffle order to OIHW rows (transpose 0 / 1).
+__device__ __forceinline__ void load_w9(const srk_pack_entry& e, int m, int kr, float (&w)[9]) {
+  const int Cps = e.src_cout >> 2;
+  if (e.transpose == 2) {
+    const int cin = e.M >> 2;                      // dx channels
+    const int g = m / cin, c = m - g * cin, pa = g >> 1, pb = g & 1;
+    const float* w9 = e.src + ((long)kr * e.src_cin + e.c_begin + c) * 9;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int r = pa == 0 ? (u == 1 ? 1 : -1) : (u == 1 ? 2 : (u == 2 ? 0 : -1));
+        const int sc = pb == 0 ? (v == 1 ? 1 : -1) : (v == 1 ? 2 : (v == 2 ? 0 : -1));
+        w[3 * u + v] = (r >= 0 && sc >= 0) ? w9[3 * r + sc] : 0.f;
+      }
+    return;
+  }
+  if (!e.transpose) {
+    int o = m;
+    if (e.ps) o = 4 * (m % Cps) + m / Cps;
+    const float* w9 = e.src + ((long)o * e.src_cin + e.c_begin + kr) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = w9[t];
+  } else {
+    int o = kr;
+    if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
+    const float* w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = w9[8 - t];
+  }
+}
+
 // fmt 6 (F(2x4, 3x3)): work item = (m, h, row position rp, q_local) -> the six column positions of 4 consecutive k: the nine taps
 // of a channel pair are read once per row position instead of once per transformed tap.
 __device__ __forceinline__ void pack_item6(const srk_pack_entry& e, long t) {
@@ -17,28 +57,17 @@ __device__ __forceinline__ void pack_item6(const srk_pack_entry& e, long t) {
   const int h = (int)(t & 1); t >>= 1;
   const int rp = (int)(t & 3); t >>= 2;
   const int q = (e.k_off >> 3) + (int)t;
-  const int Cps = e.src_cout >> 2;
   float v[6][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = 8 * q + 4 * h + j, kr = k - e.k_off;
     float g[3] = {0.f, 0.f, 0.f};
     if (m < e.M && kr >= 0 && kr < e.k_len) {
-      const float* w9;
-      if (!e.transpose) {
-        int o = m;
-        if (e.ps) o = 4 * (m % Cps) + m / Cps;
-        w9 = e.src + ((long)o * e.src_cin + e.c_begin + kr) * 9;
-      } else {
-        int o = kr;
-        if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
-        w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
-      }
+      float w[9];
+      load_w9(e, m, kr, w);
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        float c0, c1, c2;                       // column tap b of kernel rows 0, 1, 2 (data gradient: taps flipped)
-        if (!e.transpose) { c0 = w9[b]; c1 = w9[3 + b]; c2 = w9[6 + b]; }
-        else { c0 = w9[8 - b]; c1 = w9[5 - b]; c2 = w9[2 - b]; }
+        const float c0 = w[b], c1 = w[3 + b], c2 = w[6 + b];       // column tap b of window rows 0, 1, 2
         g[b] = e.scale * (rp == 0 ? c0 : rp == 1 ? 0.5f * ((c0 + c1) + c2) : rp == 2 ? 0.5f * ((c0 - c1) + c2) : c2);
       }
     }
@@ -64,11 +93,10 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
   const int Mp = (e.M + 31) & ~31;
   const int m = (int)(t % Mp); t /= Mp;
   const int h = (int)(t & 1); t >>= 1;
-  const int ntap = e.fmt == 3 ? 12 : (e.fmt == 5 ? 18 : (e.fmt == 6 ? 24 : 9));
+  const int ntap = e.fmt == 3 ? 12 : (e.fmt == 5 ? 18 : 9);
   const int tap = (int)(t % ntap); t /= ntap;
   const int ql = (int)t;                      // chunk index relative to k_off/8
   const int q = (e.k_off >> 3) + ql;
-  const int Cps = e.src_cout >> 2;
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -76,41 +104,12 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
     const int kr = k - e.k_off;               // k relative to this entry
     float val = 0.f;
     if (m < e.M && kr >= 0 && kr < e.k_len) {
-      const float* w9;                          // the 9 taps of this (output, input) channel pair
-      if (!e.transpose) {
-        int o = m;
-        if (e.ps) o = 4 * (m % Cps) + m / Cps;
-        w9 = e.src + ((long)o * e.src_cin + e.c_begin + kr) * 9;
-      } else {
-        int o = kr;
-        if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
-        w9 = e.src + ((long)o * e.src_cin + e.c_begin + m) * 9;
-      }
-      if (e.fmt == 6) {
-        // F(2x4, 3x3): 24 taps = 4 row positions (F(2,3): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2 over the kernel ROWS) x 6 column
-        // positions (F(4,3) over the row's three column taps), u = G_h w G_w^T
-        const int rp = tap / 6, p = tap - 6 * rp;
-        float g[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          float c0, c1, c2;                       // column tap b of kernel rows 0, 1, 2 (data gradient: taps flipped)
-          if (!e.transpose) { c0 = w9[b]; c1 = w9[3 + b]; c2 = w9[6 + b]; }
-          else { c0 = w9[8 - b]; c1 = w9[5 - b]; c2 = w9[2 - b]; }
-          g[b] = rp == 0 ? c0 : rp == 1 ? 0.5f * ((c0 + c1) + c2) : rp == 2 ? 0.5f * ((c0 - c1) + c2) : c2;
-        }
-        const float w0 = g[0], w1 = g[1], w2 = g[2];
-        val = p == 0 ? 0.25f * w0
-            : p == 1 ? (-1.f / 6.f) * ((w0 + w1) + w2)
-            : p == 2 ? (-1.f / 6.f) * ((w0 - w1) + w2)
-            : p == 3 ? (w0 * (1.f / 24.f) + w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
-            : p == 4 ? (w0 * (1.f / 24.f) - w1 * (1.f / 12.f)) + w2 * (1.f / 6.f)
-            : w2;
-      } else if (e.fmt == 5) {
-        // F(4,3): 18 taps = 3 kernel rows x 6 positions, u = G w
+      float w[9];
+      load_w9(e, m, kr, w);
+      if (e.fmt == 5) {
+        // F(4,3): 18 taps = 3 window rows x 6 positions, u = G w
         const int r = tap / 6, p = tap - 6 * r;
-        float w0, w1, w2;
-        if (!e.transpose) { w0 = w9[3 * r]; w1 = w9[3 * r + 1]; w2 = w9[3 * r + 2]; }
-        else { w0 = w9[8 - 3 * r]; w1 = w9[7 - 3 * r]; w2 = w9[6 - 3 * r]; }
+        const float w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
         val = p == 0 ? 0.25f * w0
             : p == 1 ? (-1.f / 6.f) * ((w0 + w1) + w2)
             : p == 2 ? (-1.f / 6.f) * ((w0 - w1) + w2)
@@ -119,23 +118,14 @@ __device__ __forceinline__ void pack_item(const srk_pack_entry& e, long t) {
             : w2;
       } else if (e.fmt == 3) {
         const int r = tap >> 2, p = tap & 3;
-        float w0, w1, w2;
-        if (!e.transpose) { w0 = w9[3 * r]; w1 = w9[3 * r + 1]; w2 = w9[3 * r + 2]; }
-        else { w0 = w9[8 - 3 * r]; w1 = w9[7 - 3 * r]; w2 = w9[6 - 3 * r]; }      // data gradient: taps flipped
+        const float w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
         val = p == 0 ? w0 : p == 1 ? 0.5f * ((w0 + w1) + w2) : p == 2 ? 0.5f * ((w0 - w1) + w2) : w2;
       } else {
-        val = e.transpose ? w9[8 - tap] : w9[tap];
+        val = w[tap];
       }
       val *= e.scale;
     }
     v[j] = val;
-  }
-  if (e.fmt == 6) {
-    // [q][channel pair of the k-half][tap][h][Mp] float2: the wino42 kernel loads a channel pair's fragments at a time
-    float2* d2 = reinterpret_cast<float2*>(e.dst);
-    d2[((((long)q * 2 + 0) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[0], v[1]);
-    d2[((((long)q * 2 + 1) * 24 + tap) * 2 + h) * Mp + m] = make_float2(v[2], v[3]);
-    return;
   }
   float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * ntap + tap) * 2 + h) * Mp + m;
   *d = make_float4(v[0], v[1], v[2], v[3]);
@@ -282,6 +272,7 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   int64_t acc = 0;
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
+    if (e[i].transpose < 0 || e[i].transpose > 2 || (e[i].transpose == 2 && ((e[i].M & 3) || e[i].ps || e[i].fmt == 1))) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
     if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5 && e[i].fmt != 6)) return SRK_ERR_BAD_ARG;
     if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;

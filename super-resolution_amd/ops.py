@@ -12,10 +12,15 @@ backward methods are written in terms of each other:
 pre-activations, conv(lrelu(z_prev)), so every node only needs its own input and output
 (discriminator_block, models.py:140-146).  Weights arrive as canonical OIHW tensors and are packed per call.
 """
+import os
+
 import torch
 
 from . import _lib as L
 from ._lib import View
+
+# stride-2 data gradients as PixelShuffle convs on dy (SRK_S2_PS_DGRAD=0: the zero-upsample form of srk_conv3x3)
+S2_PS_DGRAD = os.environ.get("SRK_S2_PS_DGRAD", "1") != "0"
 
 
 def _pack(w: torch.Tensor, transpose: bool):
@@ -45,6 +50,7 @@ class PackedConvs:
         dev = self.convs[0].weight.device
         self.fwd, self.bwd = [], []
         self.tab_f, self.tab_b = L.PackTable(dev), L.PackTable(dev)
+        self.tab_s2 = {}            # fmt -> table of the stride-2 layers' data-gradient weights in PixelShuffle-conv form
         for c in self.convs:
             co, ci = c.weight.shape[:2]
             f = torch.empty(L.packed_floats(ci, co), dtype=torch.float32, device=dev)
@@ -53,8 +59,17 @@ class PackedConvs:
             self.tab_b.add(c.weight.data, b, M=ci, k_off=0, k_len=co, K_total=co, transpose=True)
             self.fwd.append(f)
             self.bwd.append(b)
+            if S2_PS_DGRAD and tuple(c.stride) == (2, 2) and ci % 4 == 0:
+                # data gradient of the stride-2 layer = a stride-1 conv on dy with 4 * ci outputs, PixelShuffled into dx (srk.h,
+                # srk_pack_entry.transpose == 2): no zero-upsampled input, full 64-wide output tiles -> the Winograd kernels apply
+                fmt = 6 if (co % 8 == 0 and (4 * ci) % 64 == 0 and os.environ.get("SRK_WINOGRAD", "1") != "0") else 0
+                p2 = torch.empty(L.packed_floats(co, 4 * ci, fmt), dtype=torch.float32, device=dev)
+                self.tab_s2.setdefault(fmt, L.PackTable(dev, fmt)).add(c.weight.data, p2, M=4 * ci, k_off=0, k_len=co, K_total=co, transpose=2)
+                b.s2pack = (p2, fmt)
         self.tab_f.finalize()
         self.tab_b.finalize()
+        for t in self.tab_s2.values():
+            t.finalize()
 
     def refresh(self, need_bwd: bool):
         if not self.convs:
@@ -67,6 +82,8 @@ class PackedConvs:
         self.tab_f.run()
         if need_bwd:
             self.tab_b.run()
+            for t in self.tab_s2.values():
+                t.run()
 
 
 def _out_hw(h, w, stride):
@@ -96,8 +113,14 @@ def conv_dgrad_raw(dz, w, x_or_none, stride, in_slope, H, W, wpt=None):
     Ci = w.shape[1]
     dx = torch.empty(N, H, W, Ci, dtype=torch.float32, device=dz.device)
     mask = View(x_or_none) if (x_or_none is not None and in_slope != 1.0) else None
+    s2 = getattr(wpt, "s2pack", None)
     if stride == 1:
         L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=H, W=W, OH=H, OW=W, Cin=Co, Cout=Ci, mask=mask, mask_slope=in_slope)
+    elif s2 is not None and H == 2 * OH and W == 2 * OW:
+        # stride-2 layer, even extent: conv on dy with 4 * Ci outputs stored through the PixelShuffle epilogue (the mask is read
+        # at the shuffled position, i.e. at the dx pixel)
+        L.conv3x3(View(dz), s2[0], None, View(dx), N=N, H=OH, W=OW, OH=OH, OW=OW, Cin=Co, Cout=4 * Ci, ps_out=True,
+                  mask=mask, mask_slope=in_slope, wp_format=s2[1])
     else:
         L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=OH, W=OW, OH=H, OW=W, Cin=Co, Cout=Ci,
                   in_mode=L.IN_ZERO_UPSAMPLE, mask=mask, mask_slope=in_slope)

@@ -617,3 +617,25 @@ def test_small_channel_kernels_views_and_fused_epilogue(U, force_small, ci, co):
               r1=L.View(U.nhwc(r1)), beta1=0.5, r2=L.View(U.nhwc(r2, ldc=co + 4, coff=4), 4, co), beta2=-1.5, mask=L.View(U.nhwc(m)), mask_slope=0.01)
     assert U.rel_err(U.nchw(out, 4, co), ref) < TOL
     assert out[..., :4].abs().max().item() == 0.0 and out[..., 4 + co:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("ci,co,h,w,n", [(16, 16, 32, 32, 2), (32, 32, 64, 48, 1), (64, 64, 16, 16, 2), (16, 32, 8, 24, 1), (16, 16, 33, 20, 1), (16, 16, 256, 256, 1)])
+def test_stride2_dgrad_as_pixel_shuffle_conv(U, ci, co, h, w, n):
+    """Data gradient of the discriminator's stride-2 layers (models.py:144) through the transpose == 2 packing: a stride-1 conv on dy
+    with 4 * ci outputs stored through the PixelShuffle epilogue, LeakyReLU' mask of the layer below fused in; odd extents take the
+    zero-upsample form.  Against autograd on the CPU oracle."""
+    import importlib
+    ops = importlib.import_module("super-resolution_amd.ops")
+    models = importlib.import_module("super-resolution_amd.models")
+    conv = models.Conv3x3(ci, co, stride=2).cuda()
+    wt = _rand((co, ci, 3, 3), 92, 1.0 / np.sqrt(9 * ci))
+    conv.weight.data.copy_(wt)
+    x = _rand((n, ci, h, w), 91).requires_grad_(True)
+    y = O.conv3x3(O.lrelu(x, 0.2), wt, None, stride=2)
+    dy = _rand(y.shape, 93)
+    y.backward(dy)
+    pc = ops.PackedConvs([conv])
+    pc.refresh(need_bwd=True)
+    assert getattr(pc.bwd[0], "s2pack", None) is not None
+    dx = ops.conv_dgrad_raw(U.nhwc(dy), conv.weight, U.nhwc(x.detach()), 2, 0.2, h, w, wpt=pc.bwd[0])
+    assert U.rel_err(U.nchw(dx), x.grad) < TOL
