@@ -177,7 +177,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     for (int i = 0; i < 12; ++i) {
       const int c = i >> 1, nh = i & 1;
       mfma((NMT * nh + MT) * 6 + c, V[c], B[c][nh][E]);
-#ifndef W42_NO_LB
+#ifndef W42_NO_LB      // (-DW42_NO_LB / -DW42_NO_DMA: timing-only ablation builds of tools/debug/run_var.sh -- wrong results)
       if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
 #endif
 #ifndef W42_NO_DMA

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[i], V[i], acc[i], 0, 0, 0);
-#ifndef W22_NO_LDS
+#ifndef W22_NO_LDS     // (-DW22_NO_LDS / NO_XFORM / NO_DMA: timing-only ablation builds of tools/debug/run_wgvar.sh -- wrong results)
       if (i == 0) { UN[0] = ap[0]; UN[3] = ap[64]; UN[12] = ap[16 * 64]; UN[15] = ap[17 * 64]; }
       if (i == 1 || i == 2 || (top && (i == 3 || i == 4))) {
         const int r = i <= 2 ? i + 1 : i - 3;                      // rows 2, 3 first, then (top) rows 0, 1
