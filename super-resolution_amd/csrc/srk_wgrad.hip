@@ -841,9 +841,10 @@ __global__ __launch_bounds__(576) void wgrad_prereduce_kernel(const WBatch B, co
 // (64 cin columns) would be 98 % padding: this is a bandwidth-bound streaming reduction instead.  One thread per
 // output pixel (grid-stride), 16 output channels per grid.y slice: 144 + 16 FMAs per pixel in registers, then a
 // wave shuffle reduction, an LDS reduction over the 4 waves and a fixed-order second pass over the workgroups.
-constexpr int C1_CG = 16;                 // output channels per grid.y slice
+constexpr int C1_CG = 16;                 // output channels per grid.y slice (8: 94.6 us -- dy read twice in half lines)
 constexpr int C1_VALS = C1_CG * 10;       // 9 taps + bias per channel
-constexpr int C1_BLOCKS = 256;
+constexpr int C1_BLOCKS = 512;            // two 4-wave workgroups per CU (the 160 accumulators per lane allow two waves per SIMD):
+                                          // with one, every wave waits out its own load latency (101 -> 67 us at 256 x 256, batch 32)
 
 template <int S>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* part) {
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* pa
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[o][t] = 0.f; }
   const long npix = (long)B.N * B.OH * B.OW;
+  const bool dy_vec = co0 + C1_CG <= a.Cout && ((a.dy_ldc | a.dy_coff | co0) & 3) == 0 && (((uintptr_t)a.dy) & 15) == 0;
   for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
     long t = p;
     const int ow = (int)(t % B.OW); t /= B.OW;
@@ -870,9 +872,20 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const WBatch B, float* pa
       xv[tap] = v > 0.f ? v : v * a.in_slope;
     }
     const float* dyp = a.dy + p * a.dy_ldc + a.dy_coff + co0;
+    float dv[C1_CG];
+    if (dy_vec) {                                    // (workgroup-uniform) four 16-byte loads instead of sixteen dwords
+#pragma unroll
+      for (int o4 = 0; o4 < C1_CG / 4; ++o4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(dyp + 4 * o4);
+        dv[4 * o4] = t4.x; dv[4 * o4 + 1] = t4.y; dv[4 * o4 + 2] = t4.z; dv[4 * o4 + 3] = t4.w;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < C1_CG; ++o) dv[o] = (co0 + o < a.Cout) ? dyp[o] : 0.f;
+    }
 #pragma unroll
     for (int o = 0; o < C1_CG; ++o) {
-      const float d = (co0 + o < a.Cout) ? dyp[o] : 0.f;
+      const float d = dv[o];
       bacc[o] += d;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) acc[o][tap] += d * xv[tap];
