@@ -86,6 +86,21 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const unsigned wbytes = (unsigned)((long)nq * 96 * CoutP * 8);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  // weight fragments: [q][e-pair][p][c][h][CoutP] float2; the lane part of the byte offset:
+  const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 8);
+  const unsigned sB_c = (unsigned)(2 * CoutP * 8);              // one column position
+  const unsigned sB_ep = 24u * sB_c;                            // one channel pair of the chunk's k-halves
+  f32x2 P0[6][2], P1[6][2];          // weights of channels (0,1) resp. (2,3) of the chunk's k-halves: [c][nh]
+  // the first weights need nothing but the lane id: they are on their way before the halo address arithmetic starts
+  {
+    const unsigned so = (unsigned)wv * 6u * sB_c;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+        P0[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
+  }
+  __builtin_amdgcn_sched_barrier(0);
   unsigned vo[NPC];
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
@@ -131,10 +146,6 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const int slot0 = hl * HS4 + 37 * krow + 4 * tcol;
   const float* ldsA = reinterpret_cast<const float*>(smem) + (slot0 + 18 * da + (da >> 1)) * 4;
   const float* ldsB = reinterpret_cast<const float*>(smem) + (slot0 + 18 * db + (db >> 1)) * 4;
-  // weight fragments: [q][e-pair][p][c][h][CoutP] float2; the lane part of the byte offset:
-  const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 8);
-  const unsigned sB_c = (unsigned)(2 * CoutP * 8);              // one column position
-  const unsigned sB_ep = 24u * sB_c;                            // one channel pair of the chunk's k-halves
 
   f32x16 acc[12 * NMT];
   auto mfma = [&](int t, float va, float vb) {       // t is a constant after unrolling: one of the two statements survives
@@ -146,7 +157,6 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(va), "v"(vb));
   };
 
-  f32x2 P0[6][2], P1[6][2];          // weights of channels (0,1) resp. (2,3) of the chunk's k-halves: [c][nh]
   float Vc[6], Vn[6];
   f32x2 ra[6], rb[6];                // raw pixels of the current group: rows a / b of this wave's row position, a channel pair each
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -214,8 +224,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       __syncthreads();
       phase(I0{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
-      return;
-    }
+    } else {
     phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
     W42_SEG(0);
     phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I1{}, I0{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
@@ -236,22 +245,15 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     W42_SEG(7);
     phase(I1{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)
     W42_SEG(8);
+    }
   };
 
   piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{});
   if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
-  {
-    const unsigned so = (unsigned)wv * 6u * sB_c;
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
-        P0[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
-  }
   W42_STAMP(1);
   __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
 #pragma unroll
-  for (int t = 0; t < 24; ++t)
+  for (int t = 0; t < 12 * NMT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
