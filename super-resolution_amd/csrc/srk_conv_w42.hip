@@ -27,6 +27,10 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W42_XA
+#define W42_XA 1         // gaps (relative to the first transform slot of a phase) that hold the two halves of the input transform
+#define W42_XB 3
+#endif
 #ifdef SRK_STAMP
 __device__ unsigned long long* g_w42_stamps = nullptr;
 #define W42_STAMP(k) do { if (threadIdx.x == 0 && g_w42_stamps) { g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_w42_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -197,12 +201,18 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
         ra[i] = *reinterpret_cast<const f32x2*>(ldsA + off + 4 * i);
         rb[i] = *reinterpret_cast<const f32x2*>(ldsB + off + 4 * i);
       }
-      if (i == X0 + 0) { d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP]; }
-      if (i == X0 + 1) { d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP]; }
-      if (i == X0 + 2) { t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1; }
-      if (i == X0 + 3) { VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1; }
-      if (i == X0 + 4) { VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6; }
-      if (i == X0 + 5) { VN[5] = 4.f * d1 + (d5 - 5.f * d3); }
+      // the transform's VALU work sits in W42_XGAPS gaps, not spread over six: the fp32 MFMA and the vector ALU do not overlap
+      // within a wave (tools/ubench/lds_beside_mfma.hip), and every gap that holds any VALU pays a fixed restart on top
+      if (i == X0 + W42_XA) {
+        d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP];
+        d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP];
+        t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1;
+      }
+      if (i == X0 + W42_XB) {
+        VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1;
+        VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6;
+        VN[5] = 4.f * d1 + (d5 - 5.f * d3);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };

@@ -24,12 +24,26 @@ constexpr int W22_IH = W22_TH + 2, W22_IW = WTW + 2;       // 10 x 18 halo
 constexpr int W22_NHP = W22_IH * W22_IW;                   // 180
 constexpr int W22_TILE_FLOATS = 80 * 256;                  // (128 + 180) pixels x 64 channels, padded to 80 DMA slots: 81,920 B per buffer
 constexpr int W22_THREADS = 256;
+#ifndef W22_XS0
+#define W22_XS0 7        // the two MFMA gaps of a k-step that hold its vector-ALU work, and the transform group the second starts with
+#define W22_XS1 11
+#define W22_XG 5
+#endif
+
+#ifdef SRK_STAMP      // diagnostic build (make stamp; tools/stamp_w22.py): per-workgroup phase stamps.  Only OUTSIDE the tile loop: a chained node
+                      // (s_memtime, volatile asm) inside it makes the instruction selector abandon the source order of the builtin MFMAs
+__device__ unsigned long long* g_w22_stamps = nullptr;
+#define W22_STAMP(k) do { if (wv == 0 && g_w22_stamps) {   /* (wave-uniform test: a lane-divergent branch here made the compiler treat the tile contexts as divergent) */ g_w22_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_w22_stamps[blockIdx.x * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define W22_STAMP(k) do { } while (0)
+#endif
 
 template <int DYMODE>
 __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBatch B, float* part, float* pbias) {
   __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 163,840 B: all of the LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  W22_STAMP(0);
   const int hl = lane >> 5, l32 = lane & 31;
   const int wa = wv & 1, wb = wv >> 1;
   int p, chunk;
@@ -95,19 +109,37 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     }
   }
   struct TileCtx { int ow0; unsigned org_dy, org_x; __amdgpu_buffer_rsrc_t xr, dr; };
-  auto tile_ctx = [&](int tile) {
+  struct TilePos { int tx, ty, n; };
+  // Tile bookkeeping is wave-uniform scalar work that the instruction selector lets float to the head of the one-block loop
+  // body (sched_barriers only bind the machine scheduler), i.e. in front of idle matrix pipes: as tile -> (n, ty, tx) divisions,
+  // formed for tile + 1 and again for tile + 2, it was ~240 instructions per tile.  So the position is stepped incrementally (no
+  // division in the loop) and the context of tile + 2 is formed ONCE and carried into the next iteration.  (Pinning the
+  // arithmetic into empty MFMA slots with an empty volatile asm was tried: the asm nodes make the selector abandon source
+  // order for the builtin MFMAs -- every slot emptied, 60 spills.)
+  auto tile_pos = [&](int tile) {
+    TilePos q;
     int tt = tile;
-    const int tx = tt % B.tilesW; tt /= B.tilesW;
-    const int ty = tt % B.tilesH; tt /= B.tilesH;
-    const int n = tt;
-    TileCtx c;
-    const int oh0 = ty * W22_TH;
-    c.ow0 = tx * WTW;
+    q.tx = tt % B.tilesW; tt /= B.tilesW;
+    q.ty = tt % B.tilesH; q.n = tt / B.tilesH;
+    return q;
+  };
+  auto pos_step = [&](TilePos& q, bool go) {                      // q <- position of the next tile (unchanged when !go)
+    int tx = q.tx + 1, ty = q.ty, n = q.n;
+    const bool wx = tx == B.tilesW;
+    tx = wx ? 0 : tx; ty += wx ? 1 : 0;
+    const bool wy = ty == B.tilesH;
+    ty = wy ? 0 : ty; n += wy ? 1 : 0;
+    q.tx = go ? tx : q.tx; q.ty = go ? ty : q.ty; q.n = go ? n : q.n;
+  };
+  auto ctx_offsets = [&](const TilePos& q, TileCtx& c) {
+    const int oh0 = q.ty * W22_TH;
+    c.ow0 = q.tx * WTW;
     c.org_dy = (unsigned)((DYMODE == SRK_IN_UNSHUFFLE ? (2 * oh0 * 2 * B.OW + 2 * c.ow0) : (oh0 * B.OW + c.ow0)) * a.dy_ldc * 4);
     c.org_x = (unsigned)((oh0 * B.W + c.ow0) * a.x_ldc * 4);
-    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + n * x_img + a.x_coff), 0, xbytes, 0x00020000);
-    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
-    return c;
+  };
+  auto ctx_rsrcs = [&](const TilePos& q, TileCtx& c) {
+    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + q.n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + q.n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
   };
   // piece j of this wave (j: compile-time after unrolling); `live` false (wave-uniform): issued out of range -- nothing is read,
   // zeros land in a buffer nobody reads any more
@@ -115,7 +147,8 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     float* dst = smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256;
     const bool isdy = j < NDY / 4;
     const unsigned off = rel[j] + (isdy ? c.org_dy : c.org_x);
-    const bool ok = live && (unsigned)(colx[j] + c.ow0) < (unsigned)(isdy ? B.OW : B.W);
+    const int ow = live ? c.ow0 : (1 << 28);                       // (dead pieces fail the column test: one scalar select, no mask AND per piece)
+    const bool ok = (unsigned)(colx[j] + ow) < (unsigned)(isdy ? B.OW : B.W);
     wdma16(isdy ? c.dr : c.xr, dst, ok ? off : W_OOB);
   };
 
@@ -159,17 +192,20 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     if (grp == 9) { for (int q = 0; q < 4; ++q) V[8 + q] = lo[q] - up[4 + q]; }
     if (grp == 10) { for (int q = 0; q < 4; ++q) V[12 + q] = up[4 + q] - lo[4 + q]; }
   };
-  // One k-step = 16 MFMAs on (U, V); in their shadow, by hand (one sched_barrier per MFMA): slots 0-4 the raw reads of the NEXT
-  // step (buffer nb, step nk; rows 0, 1 of x only at the top of a column), slots 5-15 its transform into (UN, VN); slots 7 and
-  // 15: one DMA piece each (2 dj, 2 dj + 1) of the tile described by dc into buffer db
+  // One k-step = 16 MFMAs on (U, V).  Between them, by hand (one sched_barrier per MFMA): gaps 0-4 the raw reads of the NEXT step
+  // (buffer nb, step nk; rows 0, 1 of x only at the top of a column); gaps W22_XS0 and W22_XS1 its transform into (UN, VN) and
+  // one DMA piece each (2 dj, 2 dj + 1) of the tile described by dc into buffer db
+  TilePos pos2;                                                    // position / context of the newest tile known (tile + 2 at most)
+  TileCtx c2;
   auto kstep = [&](const float (&U)[16], const float (&V)[16], int nb, int nk, float (&UN)[16], float (&VN)[16],
-                   const TileCtx& dc, int db, int dj, bool dlive, bool next_real) {
+                   const TileCtx& dc, int db, int dj, bool dlive, bool next_real, int mk = 0, bool mk_go = false) {
     const float *ap, *bp;
     raw_ptrs(nb, nk, ap, bp);
     const bool top = (nk & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[i], V[i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                           // (the gap's work stays BEHIND its MFMA: VALU in front of it would open a second VALU gap)
 #ifndef W22_NO_LDS     // (-DW22_NO_LDS / NO_XFORM / NO_DMA: timing-only ablation builds of tools/debug/run_wgvar.sh -- wrong results)
       if (i == 0) { UN[0] = ap[0]; UN[3] = ap[64]; UN[12] = ap[16 * 64]; UN[15] = ap[17 * 64]; }
       if (i == 1 || i == 2 || (top && (i == 3 || i == 4))) {
@@ -178,29 +214,43 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
         for (int j = 0; j < 4; ++j) d[4 * r + j] = bp[(r * W22_IW + j) * 64];
       }
 #endif
+      if (mk == 1 && i == 3) { pos_step(pos2, mk_go); ctx_offsets(pos2, c2); ctx_rsrcs(pos2, c2); }
+      // ALL vector-ALU work of the step sits in W22_XSLOTS gaps (tools/ubench/lds_beside_mfma.hip: the fp32 MFMA and the vector
+      // ALU do not overlap within a wave -- a gap costs 64 + 14 + 4 n cycles for n VALU instructions, so the 14 are paid per gap
+      // that holds any; LDS reads and DMA issue are free beside the MFMAs)
 #ifndef W22_NO_XFORM
-      if (i >= 5) xform(i - 5, nk & 3, UN, VN, next_real);
+      if (i == W22_XS0) {
+#pragma unroll
+        for (int g = 0; g < W22_XG; ++g) xform(g, nk & 3, UN, VN, next_real);
+      }
+      if (i == W22_XS1) {
+#pragma unroll
+        for (int g = W22_XG; g < 11; ++g) xform(g, nk & 3, UN, VN, next_real);
+      }
 #endif
 #ifndef W22_NO_DMA
-      if (dj >= 0 && i == 7) piece(dc, db, 2 * dj, dlive);
-      if (dj >= 0 && i == 15) piece(dc, db, 2 * dj + 1, dlive);
+      if (dj >= 0 && i == W22_XS0) piece(dc, db, 2 * dj, dlive);
+      if (dj >= 0 && i == W22_XS1) piece(dc, db, 2 * dj + 1, dlive);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
+  TileCtx cn;                                                      // context of tile + 1 at the head of every iteration
   if (t_begin < t_end) {
-    const TileCtx c0 = tile_ctx(t_begin);
+    pos2 = tile_pos(t_begin);
+    TileCtx c0;
+    ctx_offsets(pos2, c0); ctx_rsrcs(pos2, c0);
 #pragma unroll
     for (int j = 0; j < NPW; ++j) piece(c0, 0, j, true);
+    pos_step(pos2, t_begin + 1 < t_end);
+    ctx_offsets(pos2, cn); ctx_rsrcs(pos2, cn);
+    c2 = cn;
   }
   __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
   __syncthreads();
   if (t_begin < t_end) {
-    if (t_begin + 1 < t_end) {                                     // (the state every tile starts in: pieces 0, 1 of the next one issued)
-      const TileCtx c1 = tile_ctx(t_begin + 1);
-      piece(c1, 1, 0, true); piece(c1, 1, 1, true);
-    }
+    if (t_begin + 1 < t_end) { piece(cn, 1, 0, true); piece(cn, 1, 1, true); }   // (the state every tile starts in: pieces 0, 1 of the next one issued)
     {
       const float *ap, *bp;
       raw_ptrs(0, 0, ap, bp);
@@ -214,28 +264,27 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     for (int grp = 0; grp < 11; ++grp) xform(grp, 0, U0, V0, true);
   }
   int b = 0;
+  W22_STAMP(1);
   for (int tile = t_begin; tile < t_end; ++tile) {
     // tile sits in buffer b, tile + 1 is in flight into b ^ 1 (issued during the previous tile); tile + 2 goes into b once the
     // barrier in front of the last k-step has released it: its pieces ride on that step and on steps 0-8 of the next tile.
-    const bool more1 = tile + 1 < t_end;
-    const TileCtx cn = tile_ctx(more1 ? tile + 1 : tile);          // (the tile whose pieces 2-19 are issued during THIS tile's steps 0-8)
+    // cn: the tile whose pieces 2-19 are issued during THIS tile's steps 0-8 (past the end: any valid context, pieces dead).
+    const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
     const bool livep = more1;
     const int bnp = b ^ 1;
 #pragma unroll
     for (int kk = 0; kk < 14; kk += 2) {
-      kstep(U0, V0, b, kk + 1, U1, V1, cn, bnp, kk < 9 ? kk + 1 : -1, livep, true);
-      kstep(U1, V1, b, kk + 2, U0, V0, cn, bnp, kk + 1 < 9 ? kk + 2 : -1, livep, true);
+      kstep(U0, V0, b, kk + 1, U1, V1, cn, bnp, kk < 9 ? kk + 1 : -1, livep, true, kk == 10 ? 1 : 0, more2);
+      kstep(U1, V1, b, kk + 2, U0, V0, cn, bnp, kk + 1 < 9 ? kk + 2 : -1, livep, true, 0, false);
     }
     kstep(U0, V0, b, 15, U1, V1, cn, bnp, -1, false, true);        // k-step 14
     __builtin_amdgcn_s_waitcnt(0x0070);                            // every piece of tile + 1 has landed (no other VMEM in flight)
     __builtin_amdgcn_s_barrier();
-    {
-      const bool more2 = tile + 2 < t_end;
-      const TileCtx c2 = tile_ctx(more2 ? tile + 2 : tile);
-      kstep(U1, V1, bnp, 0, U0, V0, c2, b, 0, more2, more1);       // k-step 15: pieces 0, 1 of tile + 2; first operands of tile + 1
-    }
+    kstep(U1, V1, bnp, 0, U0, V0, c2, b, 0, more2, more1);         // k-step 15: pieces 0, 1 of tile + 2; first operands of tile + 1
+    cn = c2;
     b ^= 1;
   }
+  W22_STAMP(2);
   __builtin_amdgcn_s_waitcnt(0x0070);
   __syncthreads();
 
@@ -272,6 +321,7 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     const float tot = bsum + __shfl_xor(bsum, 32);
     if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
+  W22_STAMP(3);
 }
 
 }  // namespace
@@ -284,3 +334,9 @@ int srk_launch_wgrad_wino22(const WBatch& B, float* part, float* pbias, hipStrea
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
+
+#ifdef SRK_STAMP
+extern "C" int srk_debug_set_w22_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w22_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#endif
