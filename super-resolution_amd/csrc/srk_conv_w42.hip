@@ -28,8 +28,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef W42_XA
-#define W42_XA 1         // gaps (relative to the first transform slot of a phase) that hold the two halves of the input transform
-#define W42_XB 3
+#define W42_XA 2         // the gap (relative to the first transform slot of a phase) that holds the input transform
 #endif
 #ifdef SRK_STAMP
 __device__ unsigned long long* g_w42_stamps = nullptr;
@@ -201,17 +200,20 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
         ra[i] = *reinterpret_cast<const f32x2*>(ldsA + off + 4 * i);
         rb[i] = *reinterpret_cast<const f32x2*>(ldsB + off + 4 * i);
       }
-      // the transform's VALU work sits in W42_XGAPS gaps, not spread over six: the fp32 MFMA and the vector ALU do not overlap
-      // within a wave (tools/ubench/lds_beside_mfma.hip), and every gap that holds any VALU pays a fixed restart on top
+      // The transform's VALU work sits in ONE gap per phase, not spread over six: the fp32 MFMA and the vector ALU do not overlap
+      // within a wave (tools/ubench/lds_beside_mfma.hip) and every gap that holds any VALU pays a fixed restart on top.  Pure
+      // arithmetic floats freely between the (volatile) MFMAs when instructions are selected, so the inputs pass through an
+      // empty volatile asm at the head of the gap and the results through one at its end.
       if (i == X0 + W42_XA) {
+        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]),
+                          "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]));
         d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP];
         d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP];
         t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1;
-      }
-      if (i == X0 + W42_XB) {
         VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1;
         VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6;
         VN[5] = 4.f * d1 + (d5 - 5.f * d3);
+        asm volatile("" : "+v"(VN[0]), "+v"(VN[1]), "+v"(VN[2]), "+v"(VN[3]), "+v"(VN[4]), "+v"(VN[5]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
