@@ -185,7 +185,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     constexpr int DJ = decltype(djc)::value, DB = decltype(dbc)::value;
     constexpr int X0 = SECOND ? 6 : 0, COMP = SECOND ? 0 : 1;       // transform: first slot, channel of the pair
     const unsigned so = (unsigned)(2 * lq + lp) * sB_ep + (unsigned)wv * 6u * sB_c;
-    float d0, d1, d2, d3, d4, d5, t1, t2, t3, t4, t5, t6;
+    float d0, d1, d2, d3, d4, d5, t1, t2, t3, t4;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int c = i >> 1, nh = i & 1;
@@ -194,6 +194,8 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
 #endif
 #ifndef W42_NO_DMA
+      // (behind the phase's weight loads: vector memory retires in order, and issued in the transform gap, ahead of them, the
+      // gather stands between every later weight load and its use -- measured +5 us per launch)
       if (DJ >= 0 && i == 11) piece(dq, DB, std::integral_constant<int, (DJ >= 0 ? DJ : 0)>{});
 #endif
       if (SECOND && i < 6) {
@@ -209,10 +211,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
                           "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]));
         d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP];
         d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP];
-        t1 = d1 + d2; t2 = d4 + d3; t3 = d1 - d2; t4 = d4 - d3; t5 = d4 - d2; t6 = d3 - d1;
-        VN[0] = 4.f * d0 + (d4 - 5.f * d2); VN[1] = t2 - 4.f * t1;
-        VN[2] = t4 + 4.f * t3; VN[3] = t5 + 2.f * t6; VN[4] = t5 - 2.f * t6;
-        VN[5] = 4.f * d1 + (d5 - 5.f * d3);
+        // B^T d of F(4,3) in 12 instructions: (4, 0, -5, 0, 1, 0 | 0, -4, -4, 1, 1, 0 | 0, 4, -4, -1, 1, 0 | 0, -2, -1, 2, 1, 0 | 0, 2, -1, -2, 1, 0 | 0, 4, 0, -5, 0, 1)
+        t1 = __builtin_fmaf(-4.f, d2, d4); t2 = __builtin_fmaf(-4.f, d1, d3); t3 = d4 - d2; t4 = d3 - d1;
+        VN[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        VN[1] = t1 + t2; VN[2] = t1 - t2;
+        VN[3] = __builtin_fmaf(2.f, t4, t3); VN[4] = __builtin_fmaf(-2.f, t4, t3);
+        VN[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
         asm volatile("" : "+v"(VN[0]), "+v"(VN[1]), "+v"(VN[2]), "+v"(VN[3]), "+v"(VN[4]), "+v"(VN[5]));
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -280,9 +284,9 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       rb[j] = *reinterpret_cast<const f32x2*>(ldsB + 4 * j);
       d[j] = ra[j][0] + sgn * rb[j][0];
     }
-    const float t1 = d[1] + d[2], t2 = d[4] + d[3], t3 = d[1] - d[2], t4 = d[4] - d[3], t5 = d[4] - d[2], t6 = d[3] - d[1];
-    Vc[0] = 4.f * d[0] + (d[4] - 5.f * d[2]); Vc[1] = t2 - 4.f * t1; Vc[2] = t4 + 4.f * t3;
-    Vc[3] = t5 + 2.f * t6; Vc[4] = t5 - 2.f * t6; Vc[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
+    const float t1 = __builtin_fmaf(-4.f, d[2], d[4]), t2 = __builtin_fmaf(-4.f, d[1], d[3]), t3 = d[4] - d[2], t4 = d[3] - d[1];   // (as in phase())
+    Vc[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4])); Vc[1] = t1 + t2; Vc[2] = t1 - t2;
+    Vc[3] = __builtin_fmaf(2.f, t4, t3); Vc[4] = __builtin_fmaf(-2.f, t4, t3); Vc[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
   }
   piece(1, 1, I0{});           // (the state every chunk starts in: piece 0 of the next chunk in flight)
   W42_SEG_RESET();

@@ -99,6 +99,57 @@ template <int N, int SRC> void runv(float* out, unsigned long long* cyc, const c
   printf("%-60s %2d VALU per MFMA: %7.1f cycles per 16 MFMAs (+%6.1f over 1024; %5.2f per VALU)\n", what, N, per, per - 1024.0, N ? (per - 1024.0) / (16 * N) : 0.0);
 }
 
+// Vector-memory instructions beside the MFMAs: N per k-step (one per gap from gap 0 on), one s_waitcnt vmcnt(0) at the end.
+// KIND 0: buffer_load_dword  1: dwordx2  2: dwordx4 (to registers; L2 hits: 64 KB walked in a ring)  3: buffer_load_dwordx4 ... lds
+template <int KIND, int N>
+__global__ __launch_bounds__(256) void km(float* out, unsigned long long* cyc, int iters, const float* src) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x16 acc[16];
+  for (int t = 0; t < 16; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float a = lane * 0.5f, b = 1.f + wv;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long pa = (unsigned long long)src;
+  i32x4 rsrc;                                          // raw buffer: base, no stride, 1 MB, the flags the library's DMA uses
+  rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa); rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((pa >> 32) & 0xffff));
+  rsrc[2] = 1 << 20; rsrc[3] = 0x00020000;
+  unsigned voff = (blockIdx.x & 7) * 65536 + wv * 16384 + lane * 16;
+  float r1[16]; f32x2 r2[16]; f32x4 r4[16];
+  for (int i = 0; i < 16; ++i) { r1[i] = 0.f; r2[i] = f32x2{0.f, 0.f}; r4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  asm volatile("s_mov_b32 m0, %0" :: "s"(__builtin_amdgcn_readfirstlane(wv * 16384)));
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+      if (i < N) {
+        if (KIND == 0) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(r1[i]) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)));
+        if (KIND == 1) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:%3" : "=v"(r2[i]) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)));
+        if (KIND == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(r4[i]) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)));
+        if (KIND == 3) asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%2 lds" :: "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)) : "memory");
+      }
+      if (i == 15) asm volatile("s_waitcnt vmcnt(0)");
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = lds[threadIdx.x];
+  for (int t = 0; t < 16; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+  for (int i = 0; i < 16; ++i) s += r1[i] + r2[i][0] + r2[i][1] + r4[i][0] + r4[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int KIND, int N> void runm(float* out, unsigned long long* cyc, const float* src, const char* what) {
+  const int iters = 2000, blocks = 256; unsigned long long h[256];
+  auto kern = km<KIND, N>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  kern<<<blocks, 256, 163840>>>(out, cyc, iters, src); (void)hipDeviceSynchronize();
+  kern<<<blocks, 256, 163840>>>(out, cyc, iters, src); (void)hipDeviceSynchronize();
+  (void)hipMemcpy(h, cyc, blocks * 8, hipMemcpyDeviceToHost);
+  double s = 0; for (int i = 0; i < blocks; ++i) s += h[i];
+  const double per = s / blocks / iters;
+  printf("%-44s %2d per 16 MFMAs: %7.1f cycles (+%6.1f over 1024; %5.1f per instruction)\n", what, N, per, per - 1024.0, N ? (per - 1024.0) / N : 0.0);
+}
+
 template <int KIND, int NR, int PER_SLOT> void run(float* out, unsigned long long* cyc, const char* what) {
   const int iters = 2000, blocks = 256; unsigned long long h[256];
   auto kern = k<KIND, NR, PER_SLOT>;
@@ -136,5 +187,13 @@ int main() {
   runv<8, 1>(out, cyc, "v_add/v_sub reading the MFMA's A / B registers");
   runv<4, 2>(out, cyc, "four dependent v_add chains");
   runv<8, 2>(out, cyc, "four dependent v_add chains");
+  float* src; (void)hipMalloc(&src, 1 << 20); (void)hipMemset(src, 0, 1 << 20);
+  runm<0, 4>(out, cyc, src, "buffer_load_dword");
+  runm<1, 4>(out, cyc, src, "buffer_load_dwordx2");
+  runm<1, 8>(out, cyc, src, "buffer_load_dwordx2");
+  runm<2, 4>(out, cyc, src, "buffer_load_dwordx4");
+  runm<2, 8>(out, cyc, src, "buffer_load_dwordx4");
+  runm<3, 2>(out, cyc, src, "buffer_load_dwordx4 ... lds");
+  runm<3, 4>(out, cyc, src, "buffer_load_dwordx4 ... lds");
   return 0;
 }
