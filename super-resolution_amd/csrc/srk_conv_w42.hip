@@ -133,10 +133,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       const int ij = c8 / Cps_in, c = c8 - ij * Cps_in;
       xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 4);
     }
-    const unsigned voff = q < nq ? vo[j] : OOB;
+    // past the last chunk the piece is issued through a descriptor of ZERO records (every lane out of range: nothing is read,
+    // zeros land in a buffer nobody reads): a scalar select instead of a per-lane one -- VALU beside the MFMAs is never free
     if (q >= nq) xso = 0;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + b * BUF4 + (wv + 4 * j) * 64), 16,
-                                             voff, xso, 0, 0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, q < nq ? xbytes : 0u, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF4 + (wv + 4 * j) * 64), 16,
+                                             vo[j], xso, 0, 0);
   };
 
   // ---- operand addressing

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     if (grp == 2) {
       U[8] = U[0] - U[12]; U[9] = a01 - a11; U[10] = a02 - a12; U[11] = U[3] - U[15];
       U[1] = a01; U[2] = a02; U[13] = a11; U[14] = a12;
-      if (do_bias) bsum += count_bias ? a01 + a11 : 0.f;        // (the operands formed behind the last tile are not real)
+      // bias: the patch sum IS U[5]; every wave adds (one instruction, no per-wave select in the loop), the bias waves store.
+      // count_bias is a literal `true` except in the last k-step of a tile (the operands formed behind the last tile are not real)
+      bsum += count_bias ? a01 + a11 : 0.f;
     }
     if (grp == 3 && pr == 0) coltf(up, 0, 0);
     if (grp == 4 && pr == 0) coltf(up, 1, 1);
