@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void km(float* out, unsigned long long* cyc, i
   rsrc[2] = 1 << 20; rsrc[3] = 0x00020000;
   unsigned voff = (blockIdx.x & 7) * 65536 + wv * 16384 + lane * 16;
   float r1[16]; f32x2 r2[16]; f32x4 r4[16];
+  int sdummy = 0;
   for (int i = 0; i < 16; ++i) { r1[i] = 0.f; r2[i] = f32x2{0.f, 0.f}; r4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   asm volatile("s_mov_b32 m0, %0" :: "s"(__builtin_amdgcn_readfirstlane(wv * 16384)));
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -127,12 +128,16 @@ __global__ __launch_bounds__(256) void km(float* out, unsigned long long* cyc, i
         if (KIND == 1) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:%3" : "=v"(r2[i]) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)));
         if (KIND == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(r4[i]) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)));
         if (KIND == 3) asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%2 lds" :: "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)) : "memory");
+        if (KIND == 4) asm volatile("s_waitcnt vmcnt(15)");                                    // (always satisfied)
+        if (KIND == 5) asm volatile("s_add_u32 %0, %0, 4" : "+s"(sdummy) :: "scc");
+        if (KIND == 6) asm volatile("s_waitcnt vmcnt(15)\n s_add_u32 %1, %1, 4\n buffer_load_dwordx2 %0, %2, %3, 0 offen offset:%4" : "=v"(r2[i]), "+s"(sdummy) : "v"(voff), "s"(rsrc), "n"(1024 * (i % 4)) : "scc");
+        if (KIND == 7) asm volatile("s_nop 0");
       }
       if (i == 15) asm volatile("s_waitcnt vmcnt(0)");
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  float s = lds[threadIdx.x];
+  float s = lds[threadIdx.x] + sdummy;
   for (int t = 0; t < 16; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
   for (int i = 0; i < 16; ++i) s += r1[i] + r2[i][0] + r2[i][1] + r4[i][0] + r4[i][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -195,5 +200,9 @@ int main() {
   runm<2, 8>(out, cyc, src, "buffer_load_dwordx4");
   runm<3, 2>(out, cyc, src, "buffer_load_dwordx4 ... lds");
   runm<3, 4>(out, cyc, src, "buffer_load_dwordx4 ... lds");
+  runm<4, 12>(out, cyc, src, "s_waitcnt vmcnt(15) (satisfied)");
+  runm<5, 12>(out, cyc, src, "s_add_u32");
+  runm<7, 12>(out, cyc, src, "s_nop 0");
+  runm<6, 12>(out, cyc, src, "s_waitcnt + s_add_u32 + buffer_load_dwordx2 (a wino42 weight-load gap)");
   return 0;
 }
