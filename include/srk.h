@@ -212,6 +212,9 @@ int srk_sum_pool_bwd(const float* dy, float* dx, int NC, int H, int W, int k, vo
 int srk_loss_workspace_bytes(size_t* out);
 int srk_sigmoid_fwd(const float* x, float* y, long n, float scale, float shift, void* stream);
 int srk_sigmoid_bwd(const float* y, const float* gy, float* dx, long n, float scale, void* stream);
+/* out[i] = g[i] * (x[i] > 0 ? 1 : slope): LeakyReLU' applied to a gradient, one pass.  Replaces the torch.where / mul / gt chain autograd
+ * builds for the double backward of `LeakyReLU(0.2)` in the gradient penalty (models.py:149,151; esrgan.py:598-606). */
+int srk_lrelu_grad_mul(const float* x, const float* g, float* out, long n, float slope, void* stream);
 int srk_soft_count_fwd(const float* x, float* out, int B, long per_image, float sigma, float val, int hard, void* workspace,
                        size_t ws_bytes, void* stream);
 int srk_soft_count_bwd(const float* x, const float* gout, float* dx, int B, long per_image, float sigma, float val, void* stream);

@@ -19,7 +19,7 @@ EXPORTS = [
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
-    "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_soft_count_fwd", "srk_soft_count_bwd",
+    "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_lrelu_grad_mul", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_jet_extract", "srk_strerror", "srk_version",
 ]
@@ -115,6 +115,7 @@ def lib():
         L.srk_jet_extract.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]
         L.srk_loss_workspace_bytes.argtypes = [C.POINTER(C.c_size_t)]
         L.srk_sigmoid_fwd.argtypes = [_fp, _fp, C.c_long, C.c_float, C.c_float, _fp]
+        L.srk_lrelu_grad_mul.argtypes = [_fp, _fp, _fp, C.c_long, C.c_float, _fp]
         L.srk_sigmoid_bwd.argtypes = [_fp, _fp, _fp, C.c_long, C.c_float, _fp]
         L.srk_soft_count_fwd.argtypes = [_fp, _fp, C.c_int, C.c_long, C.c_float, C.c_float, C.c_int, _fp, C.c_size_t, _fp]
         L.srk_soft_count_bwd.argtypes = [_fp, _fp, _fp, C.c_int, C.c_long, C.c_float, C.c_float, _fp]
@@ -406,3 +407,10 @@ def sum_pool_fwd(x, y, NC, H, W, k):
 
 def sum_pool_bwd(dy, dx, NC, H, W, k):
     check(lib().srk_sum_pool_bwd(dy.data_ptr(), dx.data_ptr(), NC, H, W, k, stream_ptr()), "srk_sum_pool_bwd")
+
+
+def lrelu_grad_mul(x, g, out, slope):
+    """out = g * LeakyReLU'(x) in one pass (srk.h: srk_lrelu_grad_mul); x, g, out contiguous fp32 of equal size."""
+    if not (x.is_contiguous() and g.is_contiguous() and out.is_contiguous()) or x.numel() != g.numel() or out.numel() != g.numel():
+        raise ValueError("lrelu_grad_mul: contiguous tensors of equal size expected")
+    check(lib().srk_lrelu_grad_mul(x.data_ptr(), g.data_ptr(), out.data_ptr(), g.numel(), float(slope), stream_ptr()), "srk_lrelu_grad_mul")

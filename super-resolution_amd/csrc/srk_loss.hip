@@ -52,6 +52,22 @@ __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restric
   }
   for (long i = (long)blockIdx.x * LT + threadIdx.x; i < n; i += (long)gridDim.x * LT) y[i] = sigmoidf(scale * x[i] + shift);
 }
+// out = g * lrelu_s'(x): the scaling the gradient penalty's double backward applies between two conv nodes (ops.py ConvDgrad.backward;
+// torch.where(x > 0, g, g * s) is three passes and a bool tensor, this is one: 2 reads + 1 write)
+__global__ void lrelu_grad_mul_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, long n, float slope, int vec) {
+  if (vec) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (long i = (long)blockIdx.x * LT + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * LT) {
+      const float4 a = x4[i], b = g4[i];
+      o4[i] = make_float4(a.x > 0.f ? b.x : b.x * slope, a.y > 0.f ? b.y : b.y * slope, a.z > 0.f ? b.z : b.z * slope, a.w > 0.f ? b.w : b.w * slope);
+    }
+    return;
+  }
+  for (long i = (long)blockIdx.x * LT + threadIdx.x; i < n; i += (long)gridDim.x * LT) out[i] = x[i] > 0.f ? g[i] : g[i] * slope;
+}
+
 __global__ void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ dx, long n, float scale, int vec) {
   if (vec) {
     const float4* y4 = reinterpret_cast<const float4*>(y);
@@ -346,6 +362,13 @@ extern "C" int srk_sigmoid_fwd(const float* x, float* y, long n, float scale, fl
   if (!x || !y || n <= 0) return SRK_ERR_BAD_ARG;
   const int vec = vec_ok(x, y, nullptr, n);
   hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ew_grid(vec ? n / 4 : n)), dim3(LT), 0, (hipStream_t)stream, x, y, n, scale, shift, vec);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+extern "C" int srk_lrelu_grad_mul(const float* x, const float* g, float* out, long n, float slope, void* stream) {
+  if (!x || !g || !out || n <= 0) return SRK_ERR_BAD_ARG;
+  const int vec = vec_ok(x, g, out, n);
+  hipLaunchKernelGGL(lrelu_grad_mul_kernel, dim3(ew_grid(vec ? n / 4 : n)), dim3(LT), 0, (hipStream_t)stream, x, g, out, n, slope, vec);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }

@@ -180,8 +180,11 @@ class ConvDgrad(torch.autograd.Function):
         dz, w, x = ctx.saved_tensors
         s = ctx.in_slope
         t = gdx.contiguous()
-        if s != 1.0:
-            t = torch.where(x > 0, t, t * s)          # lrelu' is piecewise constant: no gradient to x
+        if s != 1.0:                                  # lrelu' is piecewise constant: no gradient to x
+            _require_gpu(t)
+            scaled = torch.empty_like(t)
+            L.lrelu_grad_mul(x, t, scaled, s)         # = torch.where(x > 0, t, t * s) in one pass, no bool tensor (x: saved contiguous)
+            t = scaled
         g_dz = g_w = None
         if ctx.needs_input_grad[0]:
             g_dz = ConvPre.apply(t, w, None, ctx.stride, 1.0, ctx.wp, None)

@@ -351,6 +351,24 @@ def test_sumpool_module(srk):
     assert torch.allclose(xg.grad.cpu(), x.grad)
 
 
+@pytest.mark.parametrize("n", [4096 * 33, 1023, 7])
+def test_lrelu_grad_mul_is_the_where_chain(srk, n):
+    """srk_lrelu_grad_mul (one pass) == torch.where(x > 0, g, g * s), bit for bit, incl. x == 0 and unaligned tails: the op the
+    gradient penalty's double backward applies between two conv nodes (models.py:149,151; esrgan.py:598-606)."""
+    import importlib
+    L = importlib.import_module("super-resolution_amd")._lib
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    x[::5] = 0.0
+    gr = torch.randn(n, generator=g)
+    x, gr = x.cuda(), gr.cuda()
+    out = torch.empty_like(gr)
+    L.lrelu_grad_mul(x, gr, out, 0.2)
+    assert torch.equal(out, torch.where(x > 0, gr, gr * 0.2))
+    with pytest.raises(ValueError):
+        L.lrelu_grad_mul(x[:-1], gr, out, 0.2)
+
+
 def test_cpu_tensor_fails_loudly(srk):
     gen = srk.GeneratorRRDB(1, filters=16, num_res_blocks=1)
     with pytest.raises(RuntimeError):
