@@ -99,6 +99,7 @@ class Stepper:
         # (exact_dp), and collectives issued from side streams gained nothing with RCCL (1 rank: 136.1 vs 136.5 ms) and were
         # pathologically slow in the two-ranks-on-one-GPU gloo rehearsal.
         self._d_streams = None
+        self._d_overlap = os.environ.get("SRK_D_OVERLAP", "1") != "0"
         if os.environ.get("SRK_D_STREAMS", "1") == "1" and not distributed and torch.cuda.is_available() and len(self.discriminators) == 2:
             self._d_streams = {k: torch.cuda.Stream() for k in self.discriminators}
 
@@ -277,8 +278,17 @@ class Stepper:
     def gan_step(self, imgs_lr, imgs_hr, epsilons=None, update_g=True, update_d=True):
         # ---- generator (esrgan.py:416,457-555)
         self.optimizer_G.zero_grad(set_to_none=True)
+        ground_truth_lr = [imgs_lr, imgs_lr ** self.scaling_power]
+        pre_backward = None
         if update_g:
             loss_G, generated, ground_truth, parts = self.g_phase_loss(imgs_lr, imgs_hr)
+            # The D phase (below) needs nothing the generator's backward produces: the discriminators see the pre-update generator
+            # OUTPUT and their own weights, which the G phase only reads.  On the two discriminator streams it therefore waits for
+            # THIS point of the main stream, not for its end, and runs beside the generator's backward, whose one-workgroup-per-CU
+            # launches leave every launch gap and tail idle (single-process runs; SRK_D_OVERLAP=0: after it).  Stream order keeps it
+            # behind the G phase's own discriminator passes, which ran on the same streams.
+            if self._d_streams is not None and self._d_overlap and update_d:
+                pre_backward = torch.cuda.current_stream().record_event()
             loss_G.backward()
             if self.generator.modulewise:
                 self._sync_grads(self.generator)
@@ -291,7 +301,6 @@ class Stepper:
                 generated = [self.generator(imgs_lr), self.generator.srs]
             ground_truth = [imgs_hr, imgs_hr ** self.scaling_power]
             loss_G, parts = torch.zeros(1, device=imgs_lr.device), {}
-        ground_truth_lr = [imgs_lr, imgs_lr ** self.scaling_power]
         # ---- discriminators (esrgan.py:561-626); they see the pre-update generator output
         loss_D_tot = {}
         nan_probe = None
@@ -304,7 +313,10 @@ class Stepper:
         losses_D = {}
         for k, D in d_items:
             if two_streams:
-                self._d_streams[k].wait_stream(main)
+                if pre_backward is not None:
+                    self._d_streams[k].wait_event(pre_backward)
+                else:
+                    self._d_streams[k].wait_stream(main)
             with (torch.cuda.stream(self._d_streams[k]) if two_streams else contextlib.nullcontext()):
                 self.optimizer_D[k].zero_grad(set_to_none=True)
                 loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
