@@ -116,6 +116,33 @@ def test_gan_step_runs_and_updates_everything():
         assert not torch.equal(st.discriminators[k].model[0].weight.detach().cpu(), dsds[k]["model.0.weight"])
 
 
+def test_d_phase_beside_generator_backward_changes_no_bit():
+    """The D phase may run beside the generator's backward (train.py: it waits for the point of the main stream in front of
+    loss_G.backward(), esrgan.py:561-626 needs the pre-update generator OUTPUT only).  A schedule must not change results: three
+    iterations with the overlap on and off give bit-identical losses, generator and discriminator weights."""
+    lr, hr = O.jet_images(6, 1, 64, 64, 5, 2)
+    res = []
+    for overlap in (True, False):
+        st, _, _ = _mk("gan", res_blocks=2, filters=64, hr=64, factor=2)
+        if st._d_streams is None:
+            pytest.skip("two-stream discriminators are off (SRK_D_STREAMS=0 or data-parallel run)")
+        st._d_overlap = overlap
+        g = torch.Generator().manual_seed(3)
+        eps = [[torch.rand(6, 1, 1, 1, generator=g).cuda() for _ in range(2)] for _ in range(3)]
+        last = None
+        for it in range(3):
+            last = st.gan_step(lr.cuda(), hr.cuda(), epsilons=eps[it])
+        torch.cuda.synchronize()
+        res.append((last["g_loss"].clone(), [v.clone() for v in last["d_loss"].values()],
+                    [p.detach().clone() for p in st.generator.parameters()],
+                    [p.detach().clone() for D in st.discriminators.values() for p in D.parameters()]))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+
+
 def test_esrgan_train_entrypoint_checkpoint_roundtrip(tmp_path):
     """train(opt): warm-up + GAN iterations, reference file names for checkpoints / info.json, and resume."""
     import json

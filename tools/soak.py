@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 train = importlib.import_module("super-resolution_amd.train")
 iters = int(os.environ.get("ITERS", 600))
+torch.manual_seed(0)                      # (same initial weights every run: trajectories of two runs are comparable)
 st = train.Stepper(workload="gan", res_blocks=23, device=torch.device("cuda"), hr=256, factor=4)
 g = torch.Generator().manual_seed(0)
 pool = [(10 * torch.rand(32, 1, 256, 256, generator=g) * (torch.rand(32, 1, 256, 256, generator=g) < 0.1)).cuda() for _ in range(8)]
