@@ -19,6 +19,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
+from . import _lib as L
 from . import losses, models
 
 EPS = 1e-7   # esrgan.py:319
@@ -287,7 +288,8 @@ class Stepper:
             # THIS point of the main stream, not for its end, and runs beside the generator's backward, whose one-workgroup-per-CU
             # launches leave every launch gap and tail idle (single-process runs; SRK_D_OVERLAP=0: after it).  Stream order keeps it
             # behind the G phase's own discriminator passes, which ran on the same streams.
-            if self._d_streams is not None and self._d_overlap and update_d:
+            # (not while bench.py brackets every launch with events: the per-kernel times of the probed step must not overlap)
+            if self._d_streams is not None and self._d_overlap and update_d and not L.KernelTimer.active:
                 pre_backward = torch.cuda.current_stream().record_event()
             loss_G.backward()
             if self.generator.modulewise:
