@@ -172,17 +172,25 @@ class Stepper:
     def g_phase_loss(self, imgs_lr, imgs_hr):
         """esrgan.py:466-552 at the default flags.  Returns (loss_G, generated list, ground_truth list, parts)."""
         p = self.scaling_power
-        generated = [self.generator(imgs_lr), self.generator.srs]
         ground_truth = [imgs_hr, imgs_hr ** p]
-        gen_lr = self.pool(generated[0])
-        generated_lr = [gen_lr, gen_lr ** p]
         ground_truth_lr = [imgs_lr, imgs_lr ** p]
-        loss_G = torch.zeros(1, device=imgs_lr.device)
-        parts = {}
         # (single-process runs: the two views' discriminator passes and losses on two streams, as in the D phase; autograd runs
         # each view's backward on the stream of its forward)
         two_streams = self._d_streams is not None and all(self.lambdas[k] > 0 for k in range(2))
         main = torch.cuda.current_stream() if two_streams else None
+        # D(real) needs the ground truth only: on the discriminator streams it runs beside the generator's forward
+        early_real = {}
+        if two_streams and self._d_overlap and not L.KernelTimer.active:
+            have_gt = main.record_event()
+            for k in range(2):
+                self._d_streams[k].wait_event(have_gt)
+                with torch.cuda.stream(self._d_streams[k]), torch.no_grad():
+                    early_real[k] = self.discriminators[k](ground_truth[k], ground_truth_lr[k])
+        generated = [self.generator(imgs_lr), self.generator.srs]
+        gen_lr = self.pool(generated[0])
+        generated_lr = [gen_lr, gen_lr ** p]
+        loss_G = torch.zeros(1, device=imgs_lr.device)
+        parts = {}
         tots = {}
         for k in range(2):
             if self.lambdas[k] <= 0:
@@ -198,8 +206,11 @@ class Stepper:
                 # do not compute them
                 for q in D.parameters():
                     q.requires_grad_(False)
-                with torch.no_grad():
-                    pred_real = D(ground_truth[k], ground_truth_lr[k])
+                if k in early_real:
+                    pred_real = early_real[k]
+                else:
+                    with torch.no_grad():
+                        pred_real = D(ground_truth[k], ground_truth_lr[k])
                 pred_fake = D(generated[k], generated_lr[k])
                 for q in D.parameters():
                     q.requires_grad_(True)
