@@ -574,7 +574,15 @@ template <int DYMODE, int TERMS>
 __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B, float* part, float* pbias) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BW_BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int p = blockIdx.x, chunk = blockIdx.y;
+  // XCD-aware id -> (pixel split p, chunk), as in wgrad_f32_wino_kernel: all chunks of a split read the same x / dy tiles and must
+  // meet in ONE L2.  (As a (P, n_chunks) grid, split p of chunk c sat on XCD (p + P c) % 8: with P = 17 every chunk somewhere
+  // else -- PMC on the configs[4] workload: 1095 MB fetched per launch against ~380 algorithmic.)
+  int p, chunk;
+  {
+    const int id = blockIdx.x, nc = B.n_chunks, pm = B.P & ~7;
+    if (id < pm * nc) { const int s_ = id >> 3; p = (id & 7) + 8 * (s_ / nc); chunk = s_ - (s_ / nc) * nc; }
+    else { const int r_ = id - pm * nc; p = pm + r_ / nc; chunk = r_ - (r_ / nc) * nc; }
+  }
   const WProb& a = B.prob[B.c_prob[chunk]];
   const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
   const int cin0 = cy * 64, cout0 = cz * 64;
@@ -1110,7 +1118,7 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
       if (a0.dy_mode == SRK_IN_UNSHUFFLE) ok = ok && ((args[i].Cout >> 2) % 8 == 0);
     }
     if (!ok) return SRK_ERR_UNSUPPORTED;
-    dim3 grid(B.P, B.n_chunks);
+    dim3 grid(B.P * B.n_chunks);
     if (a0.precision == 2) {
       if (a0.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_UNSHUFFLE, 1>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
       else hipLaunchKernelGGL((wgrad_bf16x3_kernel<SRK_IN_PLAIN, 1>), grid, dim3(BW_THREADS), 0, st, B, part, pbias);
