@@ -101,7 +101,10 @@ class Stepper:
         # pathologically slow in the two-ranks-on-one-GPU gloo rehearsal.
         self._d_streams = None
         self._d_overlap = os.environ.get("SRK_D_OVERLAP", "1") != "0"
-        if os.environ.get("SRK_D_STREAMS", "1") == "1" and not distributed and torch.cuda.is_available() and len(self.discriminators) == 2:
+        # (SRK_D_STREAMS=2: also under data parallelism -- the statistic exchanges are then issued from the side streams, in the same
+        # host order on every rank; measured with one rank over RCCL only, NOT verified on several GPUs: opt-in)
+        mode = os.environ.get("SRK_D_STREAMS", "1")
+        if (mode == "2" or (mode == "1" and not distributed)) and torch.cuda.is_available() and len(self.discriminators) == 2:
             self._d_streams = {k: torch.cuda.Stream() for k in self.discriminators}
 
     # ------------------------------------------------------------------ helpers
