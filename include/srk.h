@@ -85,8 +85,15 @@ typedef struct srk_conv_args {
                                5: Winograd F(4,3)-along-W fp32 fragments (fmt = 5): half of the products, 32x16 workgroup
                                   tiles; as 3, plus in_slope == 1
                                6: 2-D Winograd F(2x4, 3x3) fp32 fragments (fmt = 6): a third of the products (F(4,3) along W
-                                  times F(2,3) along H), 32x16 workgroup tiles, one wave per SIMD; same contract as 5 */
+                                  times F(2,3) along H), 32x16 workgroup tiles, one wave per SIMD; same contract as 5
+                               7 / 8: 16-BIT ACTIVATION STORAGE, fp16 (7) / bf16 (8) MFMA operands, fp32 accumulate (BASELINE configs[4]):
+                                  x, y, r1, r2, mask point to 16-bit elements (ldc / coff in elements, multiples of 8), bias stays fp32,
+                                  wp = fragments of srk_pack_entry.fmt 7 / 8; stride 1, Cin % 16 == 0, Cout % 8 == 0, plain / unshuffle
+                                  input, in_slope == 1 */
+  int32_t flags;            /* SRK_CONV_OUT_F32: (wp_format 7 / 8 only) y is fp32 [.., y_ldc] (y_ldc / y_coff in fp32 elements, any Cout);
+                               excludes r1 / r2 / mask / ps_out -- the generator's last conv writes the fp32 image */
 } srk_conv_args;
+#define SRK_CONV_OUT_F32 1
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
 
@@ -114,7 +121,9 @@ typedef struct srk_wgrad_args {
   void* workspace; size_t workspace_bytes;
   int32_t precision;        /* 0: exact fp32 MFMA (default).  1: split-bf16 operands, 3 bf16 MFMAs per product, fp32
                                accumulate (opt-in; stride 1, Cin % 8 == 0, Cout % 8 == 0, 16-byte addressable views).
-                               2: plain bf16 operands (hi parts only), fp32 accumulate */
+                               2: plain bf16 operands (hi parts only), fp32 accumulate
+                               3 / 4: x and dy are 16-bit tensors, fp16 (3) / bf16 (4), ldc / coff in elements (multiples of 8);
+                                  dw / db stay fp32; stride 1, in_slope == 1 */
 } srk_wgrad_args;
 
 int srk_conv3x3_wgrad(const srk_wgrad_args* a, void* stream);
@@ -166,7 +175,8 @@ typedef struct srk_pack_entry {
                                (same byte size; k_off % 16 == 0);  3: Winograd fp32 fragments [K/8][3 rows x 4 pos][h][Mp][4]
                                with u = G w folded in (srk_pack_weights; 4/3 the size);  5: F(4,3) fragments [K/8][3 rows x 6 pos][h][Mp][4] (twice the
                                size);  6: F(2x4, 3x3) fragments [K/8][2 channel pairs][4 row x 6 column positions][h][Mp][2] (8/3
-                               the size).  One table = one format. */
+                               the size);  7 / 8: fp16 / bf16 fragments [K/16][tap][h][Mp64][8] of 16-bit elements, Mp64 = M rounded up
+                               to 64 (k_off % 16 == 0; transpose 0 / 1).  One table = one format. */
   int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
 } srk_pack_entry;
 
@@ -176,10 +186,15 @@ int srk_pack_plan(srk_pack_entry* host_entries, int n, int64_t* total);
 int srk_pack_weights(const srk_pack_entry* device_entries, int n, int64_t total, void* stream);
 /* the same for a table whose entries have fmt == 1 */
 int srk_pack_weights_bf16x3(const srk_pack_entry* device_entries, int n, int64_t total, void* stream);
+/* the same for a table whose entries have fmt == 7 (fp16) or 8 (bf16): 16-bit fragments of the 16-bit-storage kernels */
+int srk_pack_weights_h16(const srk_pack_entry* device_entries, int n, int64_t total, int fmt, void* stream);
 size_t srk_packed_floats(int K, int M);   /* rounds K up to 16: valid for formats 0 and 1 */
 size_t srk_packed_floats_wino(int K, int M);   /* fmt 3: 12 transformed taps instead of 9 */
 size_t srk_packed_floats_wino4(int K, int M);  /* fmt 5: 18 transformed taps */
 size_t srk_packed_floats_wino42(int K, int M); /* fmt 6: 24 transformed taps */
+size_t srk_packed_floats_h16(int K, int M);    /* fmt 7 / 8: size of the 16-bit fragment buffer in FLOAT units (4 bytes) */
+/* Test aid: rows per wave of the 16-bit-storage conv kernel (wp_format 7 / 8): 0 = by launch size (default), 2 = 8-row tiles, 4 = 16-row tiles */
+int srk_debug_set_h16_mt(int mt);
 /* 1 if srk_conv3x3 accepts wp_format == 1 for this geometry (stride 1, Cin % 16 == 0, 16-byte addressable input) */
 int srk_conv3x3_bf16x3_supported(const srk_conv_args* a);
 

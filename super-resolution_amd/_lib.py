@@ -17,7 +17,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
-    "srk_pack_weights_bf16x3", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
+    "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_lrelu_grad_mul", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
@@ -40,7 +40,7 @@ class ConvArgs(C.Structure):
         ("r2", _fp), ("r2_ldc", C.c_int32), ("r2_coff", C.c_int32), ("beta2", C.c_float),
         ("slope", C.c_float),
         ("mask", _fp), ("m_ldc", C.c_int32), ("m_coff", C.c_int32), ("mask_slope", C.c_float),
-        ("wp_format", C.c_int32),
+        ("wp_format", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -86,6 +86,10 @@ def lib():
         L.srk_packed_floats_wino4.argtypes = [C.c_int, C.c_int]
         L.srk_packed_floats_wino42.restype = C.c_size_t
         L.srk_packed_floats_wino42.argtypes = [C.c_int, C.c_int]
+        L.srk_packed_floats_h16.restype = C.c_size_t
+        L.srk_packed_floats_h16.argtypes = [C.c_int, C.c_int]
+        L.srk_debug_set_h16_mt.argtypes = [C.c_int]
+        L.srk_pack_weights_h16.argtypes = [_fp, C.c_int, C.c_int64, C.c_int, _fp]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_debug_set_conv_small.argtypes = [C.c_int]
         L.srk_debug_set_wino42_nmt.argtypes = [C.c_int]
@@ -142,12 +146,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+CONV_OUT_F32 = 1
+FMT_OF_DTYPE = {torch.float16: 7, torch.bfloat16: 8}       # wp_format / pack fmt of the 16-bit-storage kernels
+WGRAD_PRECISION_OF_DTYPE = {torch.float16: 3, torch.bfloat16: 4}
+
+
 class View:
-    """An NHWC channel-slice view ``base[pixel*ldc + coff + c]`` of a contiguous [N,H,W,ldc] fp32 tensor."""
+    """An NHWC channel-slice view ``base[pixel*ldc + coff + c]`` of a contiguous [N,H,W,ldc] tensor: fp32, or fp16 / bf16 for the
+    16-bit-storage kernels (wp_format 7 / 8; ldc / coff count elements)."""
     __slots__ = ("t", "ldc", "coff", "C")
 
     def __init__(self, t: torch.Tensor, coff: int = 0, C_: int = None):
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4, "NHWC fp32 contiguous CUDA tensor expected"
+        assert t.is_cuda and t.dtype in (torch.float32, torch.float16, torch.bfloat16) and t.is_contiguous() and t.dim() == 4, \
+            "NHWC contiguous CUDA tensor (fp32 / fp16 / bf16) expected"
         self.t = t
         self.ldc = t.shape[3]
         self.coff = coff
@@ -197,10 +208,18 @@ def _conv_kernel_name(a) -> str:
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
             ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
-            mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0):
+            mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0, flags=0):
     a = ConvArgs()
     a.in_slope = in_slope
     a.wp_format = getattr(wp, "fmt", wp_format)
+    a.flags = flags
+    if a.wp_format in (7, 8):
+        want = torch.float16 if a.wp_format == 7 else torch.bfloat16
+        for v in (x, r1, r2, mask) + (() if flags & CONV_OUT_F32 else (y,)):
+            if v is not None and v.t.dtype != want:
+                raise ValueError(f"wp_format {a.wp_format}: {want} views expected, got {v.t.dtype}")
+    elif any(v is not None and v.t.dtype != torch.float32 for v in (x, y, r1, r2, mask)):
+        raise ValueError("fp32 views expected (16-bit views go with wp_format 7 / 8)")
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout = N, H, W, OH, OW, Cin, Cout
     a.stride, a.in_mode, a.ps_out = stride, in_mode, int(ps_out)
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
@@ -332,6 +351,8 @@ def loss_workspace(device) -> torch.Tensor:
 
 def packed_floats(K: int, M: int, fmt: int = 0) -> int:
     """floats of the packed buffer for a (K inputs, M outputs) conv; fmt 3 (Winograd) carries 12 taps instead of 9."""
+    if fmt in (7, 8):
+        return lib().srk_packed_floats_h16(K, M)
     if fmt == 6:
         return lib().srk_packed_floats_wino42(K, M)
     if fmt == 5:
@@ -381,6 +402,9 @@ class PackTable:
             return
         if self._dev is None:
             self.finalize()
+        if self.fmt in (7, 8):
+            check(lib().srk_pack_weights_h16(self._dev.data_ptr(), self._n, self._total, self.fmt, stream_ptr()), "srk_pack_weights_h16")
+            return
         fn = lib().srk_pack_weights_bf16x3 if self.fmt == 1 else lib().srk_pack_weights
         check(fn(self._dev.data_ptr(), self._n, self._total, stream_ptr()), "srk_pack_weights")
 

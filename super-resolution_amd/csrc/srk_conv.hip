@@ -1085,6 +1085,8 @@ int launch_bn(const srk_conv_args& a, hipStream_t st) {
 int srk_launch_conv_bf16x3(const srk_conv_args& a, hipStream_t st);
 int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st);      // srk_conv_w42.hip
 int srk_conv_wino42_nmt(const srk_conv_args& a);
+int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st);         // srk_conv_h16.hip (wp_format 7 / 8)
+int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len);
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1104,6 +1106,7 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
     if (a.mask && a.m_ldc > ld) ld = a.m_ldc;
     if (px * ld * 4 > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
   }
+  if (a.wp_format == 7 || a.wp_format == 8) return srk_launch_conv_h16(a, st);     // 16-bit activation storage: its own checks
   if (a.wp_format == 1 || a.wp_format == 2) {
     if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return SRK_ERR_BAD_ARG;
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
@@ -1169,6 +1172,7 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
 extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_t len) {
   if (!pa || !buf || len < 8) return SRK_ERR_BAD_ARG;
   const srk_conv_args& a = *pa;
+  if (a.wp_format == 7 || a.wp_format == 8) return srk_conv_h16_name(a, buf, len);
   if (a.wp_format == 1 || a.wp_format == 2) { snprintf(buf, len, "conv3x3_bf16x3_kernel<%d, %d>", a.in_mode, a.wp_format == 1 ? 3 : 1); return SRK_OK; }
   if (a.wp_format == 5) {
     if (g_wino4_nh < 0) { const char* e = getenv("SRK_WINO4_NH"); g_wino4_nh = e ? atoi(e) : 2; }

@@ -1,0 +1,523 @@
+// srk_conv_h16.hip -- the fused 3x3 convolution with 16-BIT ACTIVATION STORAGE (fp16: wp_format 7, bf16: wp_format 8) on
+// v_mfma_f32_32x32x16_{f16,bf16} for gfx950: BASELINE configs[4]'s reduced-precision path.
+//
+// x, y, r1, r2 and the mask are 16-bit NHWC views (ldc / coff in ELEMENTS), the bias stays fp32, accumulation is fp32, the
+// master weights stay fp32 (srk_pack_weights packs them into 16-bit fragments, fmt 7 / 8, every step).  Halving the bytes per
+// activation is what this mode is for: a dense-block conv at 8 x 128 x 128 x 192 moves 50 + 17 MB instead of 101 + 34, which
+// puts it (barely) on the compute side of the bf16/fp16 matrix roof (430 FLOP/B against a ridge of ~315).
+//
+// Shape.  Workgroup = 4 waves = TH x 32 output pixels x 64 output channels, TH = 4 MT rows (MT = 4: 16 x 32, 76 KB of LDS;
+// MT = 2: 8 x 32, 58 KB), two workgroups per CU (<= 256 registers).  Wave w owns the MT ADJACENT rows MT w .. MT w + MT - 1 for
+// both 32-channel halves: 2 MT accumulator tiles.  A 32-pixel M tile is one image row, so an A fragment (32 pixels x 16
+// channels) is 32 consecutive 16-byte slots of the halo image in LDS (conflict-free ds_read_b128) and a kernel tap is an
+// address shift.  Per 16-channel chunk the (TH + 2) x 34 halo ([k-half][pixel][8 ch]: two planes) and the nine tap slices of the
+// weights ([tap][k-half][64][8]) are DMA'd global -> LDS (buffer_load ... lds, 16 B per lane) by the MFMA waves themselves, one
+// chunk ahead, two buffers, one barrier per chunk.  Within a chunk the loop runs over (column shift s, input row): an A fragment is
+// read once and feeds up to three kernel rows x two channel halves = six MFMAs; 9 MT x 2 MFMAs per 3 (MT + 2) + 18 fragment reads.
+// Epilogue: each accumulator row (32 px x 64 ch fp32) is transposed through the wave's private 8 KB of LDS so that a lane owns 8
+// consecutive channels of one pixel: bias, alpha, two residuals, LeakyReLU, LeakyReLU' mask, then ONE 16-byte store (PixelShuffle
+// folded in); the residual / mask tensors are read the same way, 16 bytes per lane, all loads of a batch ahead of its stores.
+#include "srk_internal.h"
+#include "srk_epilogue.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+typedef _Float16 h16_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float h16_f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <typename T> struct H16;
+template <> struct H16<_Float16> {
+  typedef h16_f16x8 v8;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct H16<__bf16> {
+  typedef h16_bf16x8 v8;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+// one 1-KB LDS-DMA piece: 16 bytes per lane, LDS destination = dst + 16 * lane, global source = resource base + vo (per lane) + so.
+// (A plain function on purpose: with the builtin called from inside the kernel TEMPLATE the host pass of hipcc 7.2 silently dropped
+// the kernels' host stubs -- undefined __device_stub__ symbols at load time, no diagnostic.)
+__device__ __forceinline__ void h16_dma(__amdgpu_buffer_rsrc_t rs, float4* dst, unsigned vo, unsigned so) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+}
+
+constexpr int HW_TW = 32, HW_IW = HW_TW + 2;       // tile width / halo width
+constexpr unsigned H_OOB = 0x80000000u;
+
+template <int MT> struct HGeo {
+  static constexpr int TH = 4 * MT, IH = TH + 2, NHP = IH * HW_IW;        // halo pixels (612 / 340)
+  static constexpr int HPIECES = (2 * NHP + 63) / 64;                    // 1-KB DMA pieces of the two halo planes (20 / 11)
+  static constexpr int WPIECES = 18;                                      // [tap][k-half] x 64 couts x 16 B
+  static constexpr int STAGE4 = (HPIECES + WPIECES) * 64;                 // 16-byte slots per stage
+  static constexpr int WBASE = HPIECES * 64;
+  static constexpr int NJH = (HPIECES + 3) / 4, NJW = (WPIECES + 3) / 4;  // pieces per wave (upper bounds)
+};
+
+// ------------------------------------------------------------------------------------------------------------------ epilogue
+// acc[m][t][reg]: output row MT wv + m of the tile, pixel i = (reg & 3) + 8 (reg >> 2) + 4 hl of that row, channel n0 + 32 t + l32.
+// Item (m, j), j = 0..3: pixel pl = 8 j + (lane >> 3), channels n0 + 8 (lane & 7) .. + 7.  NS = how many of r1 / r2 / mask exist.
+template <typename T, int MT, int NS, bool OUTF32>
+__device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][2], float* ls, int n, int oh0, int ow0, int n0, int wv, int lane) {
+  typedef typename H16<T>::v8 v8;
+  constexpr int TB = OUTF32 ? 1 : (NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1));    // M tiles per batch (loads ahead of stores)
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int c8 = lane & 7, plb = lane >> 3;
+  const int co = n0 + 8 * c8;
+  const int Cps_out = a.Cout >> 2;
+  int ch = co, pij = 0;
+  if (a.ps_out) { pij = co / Cps_out; ch = co - pij * Cps_out; }
+  const bool cok = OUTF32 ? (co < a.Cout) : (co + 7 < a.Cout);
+  float bq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bq[e] = 0.f;
+  if (a.bias) {
+    if (OUTF32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (co + e < a.Cout) bq[e] = a.bias[co + e];
+    } else if (cok) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bq[e] = b0[e]; bq[4 + e] = b1[e]; }
+    }
+  }
+  const float* r1p = srk_sgpr_opaque(a.r1); const float* r2p = srk_sgpr_opaque(a.r2); const float* mkp = srk_sgpr_opaque(a.mask);
+  const bool has_r1 = r1p != nullptr, has_r2 = r2p != nullptr;
+  const int r1l = srk_sgpr_opaque(a.r1_ldc), r1c = srk_sgpr_opaque(a.r1_coff), r2l = srk_sgpr_opaque(a.r2_ldc), r2c = srk_sgpr_opaque(a.r2_coff);
+  const int mkl = srk_sgpr_opaque(a.m_ldc), mkc = srk_sgpr_opaque(a.m_coff);
+  const float alpha = srk_sgpr_opaque(a.alpha), beta1 = srk_sgpr_opaque(a.beta1), beta2 = srk_sgpr_opaque(a.beta2);
+  const float slope = srk_sgpr_opaque(a.slope), mask_slope = srk_sgpr_opaque(a.mask_slope);
+  const int psr = a.ps_out ? 2 : 1;
+  const long img_px = (long)a.OH * a.OW * (a.ps_out ? 4 : 1);
+  constexpr int YB = OUTF32 ? 4 : 2;                     // bytes per output element
+  auto rsrc16 = [&](const float* p, int ldc, int coff) {    // a 16-bit tensor behind the ABI's float* fields
+    const T* q = reinterpret_cast<const T*>(p) + (long)n * img_px * ldc + coff;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(q), 0, (unsigned)((img_px * ldc - coff) * 2), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t yrs;
+  if (OUTF32) yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + (long)n * img_px * a.y_ldc + a.y_coff, 0, (unsigned)((img_px * a.y_ldc - a.y_coff) * 4), 0x00020000);
+  else yrs = rsrc16(a.y, a.y_ldc, a.y_coff);
+  __amdgpu_buffer_rsrc_t srs[NS > 0 ? NS : 1];
+  int sld[NS > 0 ? NS : 1];
+  float scoef[NS > 0 ? NS : 1], sms[NS > 0 ? NS : 1];
+  bool sres[NS > 0 ? NS : 1];
+  if constexpr (NS >= 1) {
+    const bool m0 = !has_r1 && !has_r2;
+    srs[0] = rsrc16(has_r1 ? r1p : (has_r2 ? r2p : mkp), has_r1 ? r1l : (has_r2 ? r2l : mkl), has_r1 ? r1c : (has_r2 ? r2c : mkc));
+    sld[0] = has_r1 ? r1l : (has_r2 ? r2l : mkl);
+    scoef[0] = has_r1 ? beta1 : (has_r2 ? beta2 : 0.f);
+    sms[0] = m0 ? mask_slope : 1.f; sres[0] = !m0;
+  }
+  if constexpr (NS >= 2) {
+    const bool is2 = has_r1 && has_r2;
+    srs[1] = rsrc16(is2 ? r2p : mkp, is2 ? r2l : mkl, is2 ? r2c : mkc);
+    sld[1] = is2 ? r2l : mkl;
+    scoef[1] = is2 ? beta2 : 0.f;
+    sms[1] = is2 ? 1.f : mask_slope; sres[1] = is2;
+  }
+  if constexpr (NS >= 3) {
+    srs[2] = rsrc16(mkp, mkl, mkc);
+    sld[2] = mkl; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
+  }
+  const f32x4* ls4 = reinterpret_cast<const f32x4*>(ls);
+#pragma unroll
+  for (int m0 = 0; m0 < MT; m0 += TB) {
+    int pix[TB][4];
+    unsigned valid = 0;
+    v8 sv[NS > 0 ? NS : 1][TB][4];
+    // ---- A: addresses + every residual / mask load of the batch
+#pragma unroll
+    for (int mm = 0; mm < TB; ++mm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oh = oh0 + MT * wv + m0 + mm, ow = ow0 + 8 * j + plb;
+        const bool ok = cok && oh < a.OH && ow < a.OW;
+        pix[mm][j] = (psr * oh + (pij >> 1)) * (psr * a.OW) + psr * ow + (pij & 1);
+        valid |= (ok ? 1u : 0u) << (4 * mm + j);
+      }
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+      for (int mm = 0; mm < TB; ++mm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned off = ((valid >> (4 * mm + j)) & 1) ? (unsigned)(pix[mm][j] * sld[sidx] + ch) * 2u : H_OOB;
+          sv[sidx][mm][j] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(srs[sidx], off, 0, 0));
+        }
+    // ---- B / C per tile: transpose through LDS, arithmetic, store
+#pragma unroll
+    for (int mm = 0; mm < TB; ++mm) {
+      const int m = m0 + mm;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+          ls[i * 64 + 32 * t + l32] = acc[m][t][reg];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pl = 8 * j + plb;
+        const f32x4 v0 = ls4[pl * 16 + 2 * c8], v1 = ls4[pl * 16 + 2 * c8 + 1];
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (v0[e] + bq[e]) * alpha; o[4 + e] = (v1[e] + bq[4 + e]) * alpha; }
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+          const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += scoef[sidx] * (sres[sidx] ? rv[e] : 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * slope;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+          const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= (rv[e] > 0.f ? 1.f : sms[sidx]);
+        }
+        const bool ok = (valid >> (4 * mm + j)) & 1;
+        if constexpr (OUTF32) {
+          // the fp32-output form (final conv of the generator, Cout = image channels): one dword per channel that exists
+          const unsigned base = (unsigned)(pix[mm][j] * a.y_ldc + ch) * 4u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), yrs, (ok && co + e < a.Cout) ? base + 4u * e : H_OOB, 0, 0);
+        } else {
+          h16_f32x8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = o[e];
+          const v8 hv = __builtin_convertvector(ov, v8);
+          const unsigned off = ok ? (unsigned)(pix[mm][j] * a.y_ldc + ch) * (unsigned)YB : H_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ kernel
+template <typename T, int MODE, int MT, bool OUTF32>
+__global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args a) {
+  typedef typename H16<T>::v8 v8;
+  typedef HGeo<MT> G;
+  constexpr int SMEM4 = 2 * G::STAGE4 > 2048 ? 2 * G::STAGE4 : 2048;       // >= 4 x 8 KB of epilogue scratch
+  __shared__ float4 smem[SMEM4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + HW_TW - 1) / HW_TW, tilesH = (a.OH + G::TH - 1) / G::TH;
+  int bid = blockIdx.x;
+  {
+    const int Tn = gridDim.x;                        // XCD-contiguous tile ranges: neighbouring tiles (shared halo rows) meet in one L2
+    if ((Tn & 7) == 0) bid = (bid & 7) * (Tn >> 3) + (bid >> 3);
+  }
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * G::TH, ow0 = tx * HW_TW, n0 = blockIdx.y * 64;
+  const int CoutP = (a.Cout + 63) & ~63;
+  const int nq = a.Cin >> 4;
+
+  // ---- DMA plan
+  const T* xbase = reinterpret_cast<const T*>(a.x);
+  const int Cps_in = a.Cin >> 2;
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const T* ximg = xbase + (long)n * img_elems;
+  const unsigned xbytes = (unsigned)(img_elems * 2);
+  const unsigned wbytes = (unsigned)((long)nq * 18 * CoutP * 16);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  unsigned xvo[G::NJH];
+  {
+    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+    for (int j = 0; j < G::NJH; ++j) {
+      const int slot = (wv + 4 * j) * 64 + lane;
+      const int h = slot >= G::NHP ? 1 : 0, hp = slot - h * G::NHP;
+      const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
+      const int ih = ih0 + hy, iw = iw0 + hx;
+      unsigned v = H_OOB;
+      if (slot < 2 * G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
+        long off;
+        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * h;
+        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * h;
+        v = (unsigned)(off * 2);
+      }
+      xvo[j] = v;
+    }
+  }
+  const unsigned wvo = (unsigned)((n0 + lane) * 16);
+  // One DMA piece (1 KB: 16 bytes per lane) of chunk q into buffer b.  Piece j < NJH: halo piece wv + 4 j; else weight piece
+  // (tap, k-half) = wv + 4 (j - NJH).  A piece that does not exist (past the last chunk; the waves' uneven shares) goes through a
+  // descriptor of ZERO records: nothing is read, zeros land in a slot nobody reads -- a scalar select, no branch in the main loop.
+  constexpr int NPIECE = G::NJH + G::NJW;
+  auto piece = [&](int q, auto bc, auto jc) {
+    constexpr int b = decltype(bc)::value, j = decltype(jc)::value;
+    float4* dst = smem + b * G::STAGE4;
+    if constexpr (j < G::NJH) {
+      unsigned xso = (unsigned)(16 * q * 2);
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c16 = 16 * q;
+        const int ij = c16 / Cps_in, c = c16 - ij * Cps_in;
+        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
+      }
+      const int i = wv + 4 * j;
+      const bool live = q < nq && i < G::HPIECES;            // (with zero records every lane is out of range whatever the offsets)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, live ? xbytes : 0u, 0x00020000);
+      h16_dma(rs, dst + (i < G::HPIECES ? i : 0) * 64, xvo[j], xso);
+    } else {
+      const int w = wv + 4 * (j - G::NJH);
+      const bool live = q < nq && w < G::WPIECES;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, live ? wbytes : 0u, 0x00020000);
+      h16_dma(rs, dst + G::WBASE + (w < G::WPIECES ? w : 0) * 64, wvo, (unsigned)((q * 18 + w) * CoutP * 16));
+    }
+  };
+
+  f32x16 acc[MT][2];
+  const int a_lane = hl * G::NHP + (MT * wv) * HW_IW + l32;      // + ri * IW + s
+  const int b_lane = G::WBASE + hl * 64 + l32;                    // + (tap * 2) * 64 + 32 t
+
+  // ---- main loop.  A chunk is STEPS = 3 (MT + 2) steps L = (MT + 2) s + ri: one A fragment (halo row ri, column shift s) feeds the
+  // kernel rows r with output row m = ri - r in range, both channel halves: 2 / 4 / 6 MFMAs.  Fragments are read AHEAD, by hand:
+  //   A(L + 2) at step L into a ring of four registers sets;  the six B fragments of shift s + 1 during steps ri = 1..3 of shift s
+  //   into the other of two sets;  the DMA pieces of the next chunk one per step.
+  // The last two steps of a chunk are issued BEHIND the chunk barrier and the first reads of the next chunk, so that the matrix pipe
+  // has work while those reads are in flight (with one workgroup per CU nothing else would cover them).  Everything is straight-line
+  // code (sched_barrier between the slots); two chunks per loop iteration make ring / set / buffer indices compile-time constants.
+  constexpr int SPS = MT + 2, STEPS = 3 * SPS;
+  constexpr int RINGP = (STEPS & 3);                   // ring offset of the odd chunk of a pair (18 steps: 2; 12 steps: 0)
+  v8 Af[4], Bf[2][3][2];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  auto rdA = [&](const float4* sb, int L) { return __builtin_bit_cast(v8, sb[a_lane + (L % SPS) * HW_IW + (L / SPS)]); };
+  auto rdB = [&](const float4* sb, int r, int s, int t) { return __builtin_bit_cast(v8, sb[b_lane + ((3 * r + s) * 2) * 64 + 32 * t]); };
+  auto mfma_step = [&](auto pc, auto lc) {
+    constexpr int P = decltype(pc)::value, L = decltype(lc)::value;
+    constexpr int s = L / SPS, ri = L % SPS;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int m = ri - r;
+      if (m >= 0 && m < MT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[(RINGP * P + L) & 3], Bf[(P + s) & 1][r][t], acc[m][t]);
+      }
+    }
+  };
+  auto head = [&](auto pc) {          // first fragments of a chunk of parity P: the six B fragments of shift 0, A(0), A(1)
+    constexpr int P = decltype(pc)::value;
+    const float4* sb = smem + P * G::STAGE4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) Bf[P & 1][r][t] = rdB(sb, r, 0, t);
+    Af[(RINGP * P + 0) & 3] = rdA(sb, 0);
+    Af[(RINGP * P + 1) & 3] = rdA(sb, 1);
+  };
+  auto chunk = [&](int q, auto pc) {
+    constexpr int P = decltype(pc)::value;
+    using Pc = std::integral_constant<int, P>; using Pn = std::integral_constant<int, P ^ 1>;
+    const float4* sb = smem + P * G::STAGE4;
+    auto step = [&](auto lc) {
+      constexpr int L = decltype(lc)::value;
+      constexpr int s = L / SPS, ri = L % SPS;
+      Af[(RINGP * P + L + 2) & 3] = rdA(sb, L + 2);
+      if constexpr (ri >= 1 && ri <= 3 && s < 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) Bf[(P + s + 1) & 1][ri - 1][t] = rdB(sb, ri - 1, s + 1, t);
+      }
+      if constexpr (L + 2 < NPIECE) piece(q + 1, Pn{}, std::integral_constant<int, (L + 2 < NPIECE ? L + 2 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(Pc{}, lc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - 2>{});
+    // every piece of chunk q + 1 has landed (mine: vmcnt; the others': behind the barrier) and every read of this chunk's buffer has
+    // returned (the DMA of chunk q + 2 may overwrite it)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    head(Pn{});
+    piece(q + 2, Pc{}, I0{});
+    piece(q + 2, Pc{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(Pc{}, std::integral_constant<int, STEPS - 2>{});
+    mfma_step(Pc{}, std::integral_constant<int, STEPS - 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  [&]<int... Js>(std::integer_sequence<int, Js...>) { (piece(0, I0{}, std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, NPIECE>{});
+  __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunk is in flight
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  head(I0{});
+  piece(1, I1{}, I0{});
+  piece(1, I1{}, I1{});
+  {
+    int q = 0;
+    for (; q + 1 < nq; q += 2) {
+      chunk(q, I0{});
+      chunk(q + 1, I1{});
+    }
+    if (q < nq) chunk(q, I0{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (empty) pieces and the reads of a chunk that does not exist
+  __builtin_amdgcn_s_barrier();          // the epilogue reuses the staging buffers
+  float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
+  const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
+  if constexpr (OUTF32) {
+    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+  } else {
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else h16_epilogue<T, MT, 3, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing (formats 7 / 8)
+// dst[q16][tap][h][Mp64][8] of T, k = 16 q + 8 h + e.  Work item = one (q, tap, h, m): 8 consecutive k, one 16-byte store.
+template <typename T>
+__global__ void pack_h16_kernel(const srk_pack_entry* __restrict__ tab, int n, long total) {
+  typedef typename H16<T>::v8 v8;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  int lo_ = 0, hi_ = n - 1;
+  while (lo_ < hi_) {
+    const int mid = (lo_ + hi_ + 1) >> 1;
+    if (tab[mid].elem_begin <= gid) lo_ = mid; else hi_ = mid - 1;
+  }
+  const srk_pack_entry e = tab[lo_];
+  long t = gid - e.elem_begin;
+  const int Mp = (e.M + 63) & ~63;
+  const int m = (int)(t % Mp); t /= Mp;
+  const int h = (int)(t & 1); t >>= 1;
+  const int tap = (int)(t % 9); t /= 9;
+  const int q = (e.k_off >> 4) + (int)t;
+  const int Cps = e.src_cout >> 2;
+  h16_f32x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * q + 8 * h + j;
+    const int kr = k - e.k_off;
+    float val = 0.f;
+    if (m < e.M && kr >= 0 && kr < e.k_len) {
+      if (!e.transpose) {
+        int o = m;
+        if (e.ps) o = 4 * (m % Cps) + m / Cps;
+        val = e.src[((long)o * e.src_cin + e.c_begin + kr) * 9 + tap];
+      } else {
+        int o = kr;
+        if (e.ps) o = 4 * (kr % Cps) + kr / Cps;
+        val = e.src[((long)o * e.src_cin + e.c_begin + m) * 9 + (8 - tap)];
+      }
+      val *= e.scale;
+    }
+    v[j] = val;
+  }
+  const v8 hv = __builtin_convertvector(v, v8);
+  float4* d = reinterpret_cast<float4*>(e.dst) + (((long)q * 9 + tap) * 2 + h) * Mp + m;
+  *d = __builtin_bit_cast(float4, hv);
+}
+
+int g_h16_mt = -1;
+
+#define H16_LAUNCH(T, MODE, MT)                                                                                        \
+  do {                                                                                                                 \
+    if (a.flags & SRK_CONV_OUT_F32) hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, true>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, false>), grid, dim3(256), 0, st, a);                      \
+  } while (0)
+
+int launch_h16_any(const srk_conv_args& a, int mt, hipStream_t st) {
+  const int tilesW = srk_div_up(a.OW, HW_TW), tilesH = srk_div_up(a.OH, 4 * mt);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+  const bool un = a.in_mode == SRK_IN_UNSHUFFLE;
+  if (a.wp_format == 7) {
+    if (mt == 4) { if (un) H16_LAUNCH(_Float16, 1, 4); else H16_LAUNCH(_Float16, 0, 4); }
+    else { if (un) H16_LAUNCH(_Float16, 1, 2); else H16_LAUNCH(_Float16, 0, 2); }
+  } else {
+    if (mt == 4) { if (un) H16_LAUNCH(__bf16, 1, 4); else H16_LAUNCH(__bf16, 0, 4); }
+    else { if (un) H16_LAUNCH(__bf16, 1, 2); else H16_LAUNCH(__bf16, 0, 2); }
+  }
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
+#undef H16_LAUNCH
+
+}  // namespace
+
+extern "C" int srk_debug_set_h16_mt(int mt) { g_h16_mt = (mt == 2 || mt == 4) ? mt : 0; return SRK_OK; }
+
+// Rows per wave: 16-row tiles (MT = 4: fewer halo rows and weight reads per MFMA) when they still give every CU two workgroups,
+// else 8-row tiles.  SRK_H16_MT = 2 | 4 / srk_debug_set_h16_mt force one (A/B measurements, tests).
+int srk_conv_h16_mt(const srk_conv_args& a) {
+  if (g_h16_mt < 0) { const char* e = getenv("SRK_H16_MT"); g_h16_mt = e ? atoi(e) : 0; }
+  if (g_h16_mt == 2 || g_h16_mt == 4) return g_h16_mt;
+  const long wg16 = (long)a.N * srk_div_up(a.OH, 16) * srk_div_up(a.OW, HW_TW) * (srk_round_up(a.Cout, 64) / 64);
+  return wg16 >= 512 ? 4 : 2;
+}
+
+int srk_conv_h16_check(const srk_conv_args& a) {
+  if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
+  if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cin % 16) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+  if (a.OH != a.H || a.OW != a.W) return SRK_ERR_BAD_ARG;
+  if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 16))) return SRK_ERR_UNSUPPORTED;
+  if ((a.x_ldc % 8) || (a.x_coff % 8) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
+  const bool f32o = a.flags & SRK_CONV_OUT_F32;
+  if (f32o) {
+    if (a.r1 || a.r2 || a.mask || a.ps_out) return SRK_ERR_UNSUPPORTED;
+    if (((uintptr_t)a.y) & 3) return SRK_ERR_ALIGNMENT;
+  } else {
+    if (a.Cout % 8) return SRK_ERR_UNSUPPORTED;
+    if (a.ps_out && ((a.Cout & 3) || ((a.Cout >> 2) % 8))) return SRK_ERR_UNSUPPORTED;
+    if ((a.y_ldc % 8) || (a.y_coff % 8) || (((uintptr_t)a.y) & 15)) return SRK_ERR_ALIGNMENT;
+    if (a.bias && (((uintptr_t)a.bias) & 15)) return SRK_ERR_ALIGNMENT;
+    if (a.r1 && ((a.r1_ldc % 8) || (a.r1_coff % 8) || (((uintptr_t)a.r1) & 15))) return SRK_ERR_ALIGNMENT;
+    if (a.r2 && ((a.r2_ldc % 8) || (a.r2_coff % 8) || (((uintptr_t)a.r2) & 15))) return SRK_ERR_ALIGNMENT;
+    if (a.mask && ((a.m_ldc % 8) || (a.m_coff % 8) || (((uintptr_t)a.mask) & 15))) return SRK_ERR_ALIGNMENT;
+  }
+  // one image of every tensor is addressed through a 32-bit buffer resource
+  if ((long)a.H * a.W * a.x_ldc * 2 * (a.in_mode == SRK_IN_UNSHUFFLE ? 4 : 1) > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
+  {
+    const long px = (long)a.OH * a.OW * (a.ps_out ? 4 : 1);
+    long ld = (long)a.y_ldc * (f32o ? 2 : 1);
+    if (a.r1 && a.r1_ldc > ld) ld = a.r1_ldc;
+    if (a.r2 && a.r2_ldc > ld) ld = a.r2_ldc;
+    if (a.mask && a.m_ldc > ld) ld = a.m_ldc;
+    if (px * ld * 2 > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
+  }
+  return SRK_OK;
+}
+
+int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st) {
+  const int rc = srk_conv_h16_check(a);
+  if (rc) return rc;
+  const int mt = srk_conv_h16_mt(a);
+  return launch_h16_any(a, mt, st);
+}
+
+int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len) {
+  snprintf(buf, len, "conv3x3_h16_kernel<%s, %d, %d, %s>", a.wp_format == 7 ? "_Float16" : "__bf16", a.in_mode, srk_conv_h16_mt(a),
+           (a.flags & SRK_CONV_OUT_F32) ? "true" : "false");
+  return SRK_OK;
+}
+
+int srk_launch_pack_h16(const srk_pack_entry* dev, int n, int64_t total, int fmt, hipStream_t st) {
+  if (fmt == 7) hipLaunchKernelGGL(pack_h16_kernel<_Float16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dev, n, (long)total);
+  else hipLaunchKernelGGL(pack_h16_kernel<__bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dev, n, (long)total);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}

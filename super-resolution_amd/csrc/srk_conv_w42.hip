@@ -124,7 +124,6 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       vo[j] = v;
     }
   }
-  // (a piece past the last chunk is issued with an out-of-range lane offset: nothing is read, zeros land in a buffer nobody reads)
   auto piece = [&](int q, int b, auto jc) {
     constexpr int j = decltype(jc)::value;
     unsigned xso = (unsigned)(8 * q * 4);
@@ -251,7 +250,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     W42_SEG(2);
     phase(I1{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I4{}, q + 1, Bn{});
     W42_SEG(3);
-    phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (past the end: out-of-range loads return 0)
+    phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (behind the last chunk: pair 0 of chunk nq is fetched from the padding srk_packed_floats_wino42 reserves and never used)
     W42_SEG(4);
     phase(I0{}, I3{}, Vn, P1, Yes{}, Bc{}, I1{}, I1{}, Vc, No{}, 0, 0, P0, IN{}, 0, Bc{});
     W42_SEG(5);

@@ -264,7 +264,14 @@ extern "C" size_t srk_packed_floats_wino4(int K, int M) {
 }
 
 extern "C" size_t srk_packed_floats_wino42(int K, int M) {
-  return (size_t)srk_div_up(K, 16) * 2 * 24 * 2 * srk_round_up(M, 32) * 4;
+  // + one channel pair (24 positions x 2 k-halves x Mp float2) of padding: the wino42 main loop prefetches pair 0 of chunk
+  // q + 1 unconditionally (branch-free), i.e. of chunk nq behind the last one, through the SCALAR offset of its buffer loads,
+  // which the range check of a raw buffer does not cover.  The values are never used; the bytes must be mapped.
+  return (size_t)srk_div_up(K, 16) * 2 * 24 * 2 * srk_round_up(M, 32) * 4 + (size_t)24 * 2 * srk_round_up(M, 32) * 2;
+}
+
+extern "C" size_t srk_packed_floats_h16(int K, int M) {
+  return (size_t)srk_div_up(K, 16) * 9 * 2 * srk_round_up(M, 64) * 4;     // 16 bytes per (k-half, tap, output) slot
 }
 
 extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
@@ -272,20 +279,28 @@ extern "C" int srk_pack_plan(srk_pack_entry* e, int n, int64_t* total) {
   int64_t acc = 0;
   for (int i = 0; i < n; ++i) {
     if (!e[i].src || !e[i].dst || e[i].M <= 0 || e[i].k_len <= 0 || (e[i].k_off & 7)) return SRK_ERR_BAD_ARG;
-    if (e[i].transpose < 0 || e[i].transpose > 2 || (e[i].transpose == 2 && ((e[i].M & 3) || e[i].ps || e[i].fmt == 1))) return SRK_ERR_BAD_ARG;
+    const bool f16b = e[i].fmt == 1 || e[i].fmt == 7 || e[i].fmt == 8;       // 16-channel chunks of 16-bit elements
+    if (e[i].transpose < 0 || e[i].transpose > 2 || (e[i].transpose == 2 && ((e[i].M & 3) || e[i].ps || f16b))) return SRK_ERR_BAD_ARG;
     if (e[i].ps && (e[i].src_cout & 3)) return SRK_ERR_BAD_ARG;
-    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5 && e[i].fmt != 6)) return SRK_ERR_BAD_ARG;
-    if (e[i].fmt == 1 && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
+    if (e[i].fmt != e[0].fmt || (e[i].fmt != 0 && e[i].fmt != 1 && e[i].fmt != 3 && e[i].fmt != 5 && e[i].fmt != 6 && e[i].fmt != 7 && e[i].fmt != 8)) return SRK_ERR_BAD_ARG;
+    if (f16b && (e[i].k_off & 15)) return SRK_ERR_BAD_ARG;
     e[i].elem_begin = acc;
     // chunks covered: the last entry of a dst owns the zero-filled tail of the final chunk
-    const int ck = e[i].fmt == 1 ? 16 : 8;
+    const int ck = f16b ? 16 : 8;
     int k_end = e[i].k_off + e[i].k_len;
     int nq = srk_div_up(k_end, ck) - e[i].k_off / ck;
     // fmt 0 with K not a multiple of 16: also zero the second half of the last 16-chunk (buffers are sized for 16)
+    if (e[i].fmt == 7 || e[i].fmt == 8) { acc += (int64_t)nq * 9 * 2 * srk_round_up(e[i].M, 64); continue; }
     acc += (int64_t)nq * (e[i].fmt == 3 ? 12 : (e[i].fmt == 5 ? 18 : (e[i].fmt == 6 ? 4 : 9))) * 2 * srk_round_up(e[i].M, 32);   // (fmt 6: one item per row position)
   }
   *total = acc;
   return SRK_OK;
+}
+
+int srk_launch_pack_h16(const srk_pack_entry* dev, int n, int64_t total, int fmt, hipStream_t st);
+extern "C" int srk_pack_weights_h16(const srk_pack_entry* dev, int n, int64_t total, int fmt, void* stream) {
+  if (!dev || n <= 0 || total <= 0 || (fmt != 7 && fmt != 8)) return SRK_ERR_BAD_ARG;
+  return srk_launch_pack_h16(dev, n, total, fmt, (hipStream_t)stream);
 }
 
 extern "C" int srk_pack_weights(const srk_pack_entry* dev, int n, int64_t total, void* stream) {

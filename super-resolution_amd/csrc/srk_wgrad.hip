@@ -979,6 +979,8 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   static int wino22_env = -1;
   if (wino22_env < 0) { const char* e = getenv("SRK_WGRAD_WINO22"); wino22_env = e ? atoi(e) : 1; }
   if (B.wino && wino22_env) { B.wino = 2; TH = W22_TH; }
+  const bool h16 = a0.precision == 3 || a0.precision == 4;        // 16-bit storage (srk_wgrad_h16.hip): 8-row tiles
+  if (h16) TH = W16_TH;
   B.tilesW = srk_div_up(a0.OW, WTW);
   B.tilesH = srk_div_up(a0.OH, TH);
   B.total_tiles = a0.N * B.tilesH * B.tilesW;
@@ -986,6 +988,9 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   static int wino_target = -1;        // workgroups of a Winograd launch (A/B: finer splits interleave better with the conv chain when the launch runs beside it)
   if (wino_target < 0) { const char* e = getenv("SRK_WGRAD_WINO_TARGET"); wino_target = e ? atoi(e) : 256; }
   if (B.wino) target = wino_target / nc;
+  static int h16_target = -1;         // workgroups of a 16-bit-storage launch (two per CU)
+  if (h16_target < 0) { const char* e = getenv("SRK_WGRAD_H16_TARGET"); h16_target = e ? atoi(e) : 512; }
+  if (h16) target = h16_target / nc;
   if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not
@@ -1129,6 +1134,21 @@ extern "C" int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void
     SRK_CHECK_LAUNCH();
     return launch_reduce(B, part, pbias, st);
   }
+  if (a0.precision == 3 || a0.precision == 4) {
+    // 16-bit storage: stride 1, 16-byte addressable views of 8-channel groups (channels zero-padded to 8 by the caller)
+    if (a0.stride != 1) return SRK_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+      const srk_wgrad_args& q = args[i];
+      if (q.precision != a0.precision || q.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+      if ((q.x_ldc % 8) || (q.x_coff % 8) || (q.dy_ldc % 8) || (q.dy_coff % 8) || (((uintptr_t)q.x | (uintptr_t)q.dy) & 15)) return SRK_ERR_ALIGNMENT;
+      if (a0.dy_mode == SRK_IN_UNSHUFFLE && ((q.Cout >> 2) % 8)) return SRK_ERR_UNSUPPORTED;
+      if (srk_round_up(q.Cin, 8) > q.x_ldc - q.x_coff) return SRK_ERR_BAD_ARG;
+      if (a0.dy_mode != SRK_IN_UNSHUFFLE && srk_round_up(q.Cout, 8) > q.dy_ldc - q.dy_coff) return SRK_ERR_BAD_ARG;
+    }
+    rc = srk_launch_wgrad_h16(B, a0.precision, part, pbias, st);
+    if (rc) return rc;
+    return launch_reduce(B, part, pbias, st);
+  }
   if (a0.precision != 0) return SRK_ERR_UNSUPPORTED;
   if (a0.dy_mode == SRK_IN_UNSHUFFLE) {
     if (!vec) return SRK_ERR_ALIGNMENT;
@@ -1150,6 +1170,7 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
   if (a0.precision == 1 || a0.precision == 2) { snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d>", a0.dy_mode, a0.precision == 1 ? 3 : 1); return SRK_OK; }
+  if (a0.precision == 3 || a0.precision == 4) { snprintf(buf, len, "wgrad_h16_kernel<%s, %d>", a0.precision == 3 ? "_Float16" : "__bf16", a0.dy_mode); return SRK_OK; }
   if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d>", a0.dy_mode); return SRK_OK; }
   if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
   int ksp = 1;

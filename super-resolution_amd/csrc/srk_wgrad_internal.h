@@ -38,7 +38,9 @@ __device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_d
 }
 
 constexpr int W22_TH = 8;                                  // pixel rows per tile of the 2-D Winograd kernel (srk_wgrad_w22.hip)
+constexpr int W16_TH = 8;                                  // pixel rows per tile of the 16-bit-storage kernel (srk_wgrad_h16.hip)
 
 }  // namespace srkw
 
 int srk_launch_wgrad_wino22(const srkw::WBatch& B, float* part, float* pbias, hipStream_t st);
+int srk_launch_wgrad_h16(const srkw::WBatch& B, int precision, float* part, float* pbias, hipStream_t st);   // precision 3 (fp16) / 4 (bf16)

@@ -22,8 +22,14 @@ G_SLOPE = 0.01            # nn.LeakyReLU() default slope (models.py:21,88,98)
 INNER_RES_SCALE = 0.2     # DenseResidualBlock.res_scale; RRDB never forwards its own (models.py:49)
 
 
-def _empty(*shape, device):
-    return torch.empty(*shape, dtype=torch.float32, device=device)
+def _empty(*shape, device, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
+# precision modes with 16-BIT ACTIVATION STORAGE (BASELINE configs[4]): every activation / gradient buffer of the generator is
+# fp16 ("fp16": with loss scaling, train.Stepper) or bf16 ("bf16s"); weights stay fp32 Parameters (packed into 16-bit fragments
+# every step), accumulation is fp32, weight gradients come out in fp32.  Kernels: csrc/srk_conv_h16.hip, srk_wgrad_h16.hip.
+H16_DTYPE = {"fp16": torch.float16, "bf16s": torch.bfloat16}
 
 
 class _Flat:
@@ -85,6 +91,17 @@ class GeneratorEngine:
         # single-process runs, off under data parallelism (the bucket all-reduces would move to the side stream with them: never
         # measured on more than one GPU); SRK_OVERLAP_WGRAD=0 | 1 forces either.
         self._overlap_env = os.environ.get("SRK_OVERLAP_WGRAD")
+
+    @property
+    def act_dtype(self):
+        """storage type of the activation / gradient buffers"""
+        return H16_DTYPE.get(self.precision, torch.float32)
+
+    def _wprec(self):
+        """srk_wgrad_args.precision of this mode (0 exact fp32, 1 split-bf16, 2 bf16 operands, 3 / 4 fp16 / bf16 storage)"""
+        if self.precision in H16_DTYPE:
+            return L.WGRAD_PRECISION_OF_DTYPE[H16_DTYPE[self.precision]]
+        return {"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if self.gen.filters % 8 == 0 else 0
 
     @property
     def overlap_wgrad(self) -> bool:
@@ -193,12 +210,19 @@ class GeneratorEngine:
         F_, C_ = g.filters, g.channels
         self.flat_f, self.flat_b = _Flat(), _Flat()
         # one table per (direction, fragment format)
-        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6)}
-        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6)}
+        self.tab_f = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6, 7, 8)}
+        self.tab_b = {f: L.PackTable(device, f) for f in (0, 1, 3, 5, 6, 7, 8)}
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
         bf = self.precision in ("bf16x3", "bf16")
+        h16 = self.precision in H16_DTYPE          # 16-bit storage: ONE format for every conv, image-side channels zero-padded to 16
+        hfmt = L.FMT_OF_DTYPE[H16_DTYPE[self.precision]] if h16 else 0
+        if h16 and F_ % 16 != 0:
+            raise NotImplementedError("the 16-bit-storage modes need filters % 16 == 0")
         self._built_precision = self.precision
+
+        def kpad(k):
+            return (k + 15) // 16 * 16 if h16 else k
 
         # exact-fp32 mode: stride-1 convs with 64-multiple outputs run the Winograd F(2,3)-along-W kernel (2/3 of the MFMAs)
         wino = (not bf) and os.environ.get("SRK_WINOGRAD", "1") != "0"
@@ -209,6 +233,8 @@ class GeneratorEngine:
 
         def fmt_of(K, M, up=1):
             """fragment format of a conv with K inputs, M outputs running at `up` x the LR resolution"""
+            if h16:
+                return hfmt
             if bf:
                 return 1 if (K % 16 == 0 and M >= 16) else 0
             if not (wino and L.wino_eligible(K, M)):
@@ -219,18 +245,18 @@ class GeneratorEngine:
 
         def simple(name, conv, ps=False, need_bwd=True, up=1):
             co, ci = conv.weight.shape[:2]
-            ff = fmt_of(ci, co, up) if (not ps or (co // 4) % 4 == 0) else 0
-            fi = self.flat_f.reserve(L.packed_floats(ci, co, ff))
+            ff = fmt_of(ci, co, up) if (h16 or not ps or (co // 4) % 4 == 0) else 0
+            fi = self.flat_f.reserve(L.packed_floats(kpad(ci), co, ff))
             self.fmt_f[fi] = ff
-            jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=ci, ps=ps)))
+            jobs_f.append((conv.weight, fi, dict(M=co, k_off=0, k_len=ci, K_total=kpad(ci), ps=ps)))
             bi = None
             if need_bwd:
-                fb = fmt_of(co, ci, up) if (not ps or (co // 4) % 16 == 0) else 0
+                fb = fmt_of(co, ci, up) if (h16 or not ps or (co // 4) % 16 == 0) else 0
                 if fb in (3, 5, 6) and conv.stride[0] != 1:
                     fb = 0
-                bi = self.flat_b.reserve(L.packed_floats(co, ci, fb))
+                bi = self.flat_b.reserve(L.packed_floats(kpad(co), ci, fb))
                 self.fmt_b[bi] = fb
-                jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=co, transpose=True, ps=ps)))
+                jobs_b.append((conv.weight, bi, dict(M=ci, k_off=0, k_len=co, K_total=kpad(co), transpose=True, ps=ps)))
             return fi, bi
 
         def drb(d, s5, up=1):
@@ -363,7 +389,7 @@ class GeneratorEngine:
             conv = getattr(d, f"b{k}")[0]
             probs.append(dict(x=View(D, 0, k * F_), dy=View(E, (5 - k) * F_, F_), dw=grads[conv.weight], db=grads[conv.bias],
                               Cin=k * F_, Cout=F_, scale=(pk.s5 if k == 5 else 1.0) * self._grad_scale))
-        wprec = {"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0
+        wprec = self._wprec()
         self._on_side(lambda: L.conv3x3_wgrad_batched(probs, N=N, H=H, W=W, OH=H, OW=W, precision=wprec), (D, E))
 
     def _on_side(self, fn, tensors):
@@ -403,10 +429,10 @@ class GeneratorEngine:
             for j, d in enumerate(rr.dense_blocks):
                 last = (i == n_r - 1 and j == 2)
                 if last:
-                    nxt = _empty(N, H, W, F_, device=dev)
+                    nxt = _empty(N, H, W, F_, device=dev, dtype=self.act_dtype)
                     out = View(nxt)
                 else:
-                    nxt = _empty(N, H, W, 5 * F_, device=dev)
+                    nxt = _empty(N, H, W, 5 * F_, device=dev, dtype=self.act_dtype)
                     out = View(nxt, 0, F_)
                 self._drb_forward(d, packs[i][j], cur, out, geo, View(first, 0, F_) if j == 2 else None, rr.res_scale)
                 if not last:
@@ -421,7 +447,7 @@ class GeneratorEngine:
         dev = g_out.device
         n_r = len(rrdbs)
         # E buffer of block (i,2) must stay alive until block (i,0) finishes (it is the outer residual G)
-        E_next = _empty(N, H, W, 5 * F_, device=dev)
+        E_next = _empty(N, H, W, 5 * F_, device=dev, dtype=self.act_dtype)
         E_next[..., :F_].copy_(g_out)
         result = None
         for i in range(n_r - 1, -1, -1):
@@ -432,10 +458,10 @@ class GeneratorEngine:
                 D = bufs[3 * i + j]
                 final = (i == 0 and j == 0)
                 if final:
-                    result = _empty(N, H, W, F_, device=dev)
+                    result = _empty(N, H, W, F_, device=dev, dtype=self.act_dtype)
                     gx = View(result)
                 else:
-                    E_prev = _empty(N, H, W, 5 * F_, device=dev)
+                    E_prev = _empty(N, H, W, 5 * F_, device=dev, dtype=self.act_dtype)
                     gx = View(E_prev, 0, F_)
                 self._drb_backward(rr.dense_blocks[j], packs[i][j], D, E_cur, gx, geo,
                                    beta_self=(rr.res_scale if j == 2 else 1.0),
@@ -466,10 +492,18 @@ class GeneratorEngine:
             x_nhwc = _empty(N, H, W, C_, device=dev)
             L.nchw_to_nhwc(x, View(x_nhwc), N, C_, H, W)
         geo = (N, H, W)
-        D0 = _empty(N, H, W, 5 * F_, device=dev)
+        h16 = self.precision in H16_DTYPE
+        cin1 = C_
+        if h16:
+            # 16-bit storage: the image enters zero-padded to one 16-channel chunk (conv1's packed weights are padded alike)
+            cin1 = 16
+            x_pad = torch.zeros(N, H, W, cin1, dtype=self.act_dtype, device=dev)
+            x_pad[..., :C_] = x_nhwc
+            x_nhwc = x_pad
+        D0 = _empty(N, H, W, 5 * F_, device=dev, dtype=self.act_dtype)
         # conv1 -> slice 0 of the first dense buffer (= out1, also the trunk skip; models.py:123)
         L.conv3x3(View(x_nhwc), self.wf(self.idx["conv1"][0]), g.conv1.bias.data, View(D0, 0, F_), N=N, H=H, W=W, OH=H, OW=W,
-                  Cin=C_, Cout=F_)
+                  Cin=cin1, Cout=F_)
         if len(g.res_blocks) > 0:
             bufs, trunk = self._rrdb_chain_forward(list(g.res_blocks), self.drbs, D0, geo, need_grad)
             trunk_v = View(trunk)
@@ -477,7 +511,7 @@ class GeneratorEngine:
             bufs, trunk = [D0], D0
             trunk_v = View(D0, 0, F_)
         # conv2 + trunk skip (models.py:125-126)
-        feat = _empty(N, H, W, F_, device=dev)
+        feat = _empty(N, H, W, F_, device=dev, dtype=self.act_dtype)
         L.conv3x3(trunk_v, self.wf(self.idx["conv2"][0]), g.conv2.bias.data, View(feat), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_,
                   r1=View(D0, 0, F_), beta1=1.0)
         # upsampling: conv F->4F + LeakyReLU + PixelShuffle(2) fused into the store (models.py:86-90)
@@ -486,10 +520,10 @@ class GeneratorEngine:
         for u in range(g.num_upsample):
             last_up = (u == g.num_upsample - 1)
             if last_up and g.num_final_layer_res > 0:
-                nxt = _empty(N, 2 * h, 2 * w, 5 * F_, device=dev)   # doubles as first dense buffer of the final RRDBs
+                nxt = _empty(N, 2 * h, 2 * w, 5 * F_, device=dev, dtype=self.act_dtype)   # doubles as first dense buffer of the final RRDBs
                 yv = View(nxt, 0, F_)
             else:
-                nxt = _empty(N, 2 * h, 2 * w, F_, device=dev)
+                nxt = _empty(N, 2 * h, 2 * w, F_, device=dev, dtype=self.act_dtype)
                 yv = View(nxt)
             L.conv3x3(View(cur) if cur.shape[3] == F_ else View(cur, 0, F_), self.wf(self.idx[f"up{u}"][0]), self.ps_bias[u], yv,
                       N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, ps_out=True, slope=G_SLOPE)
@@ -500,18 +534,18 @@ class GeneratorEngine:
             if g.num_upsample == 0:
                 raise NotImplementedError("num_final_layer_res > 0 requires num_upsample >= 1 in this build")
             fbufs, fout = self._rrdb_chain_forward(list(g.res_blocks_final), self.drbs_final, cur, (N, h, w), need_grad)
-            pre3 = _empty(N, h, w, F_, device=dev)
+            pre3 = _empty(N, h, w, F_, device=dev, dtype=self.act_dtype)
             torch.add(fout, cur[..., :F_], out=pre3)      # out = out3 + out (models.py:130)
             fin = (fbufs, pre3)
             cur_v = View(pre3)
         else:
             cur_v = View(cur)
-        h3 = _empty(N, h, w, F_, device=dev)
+        h3 = _empty(N, h, w, F_, device=dev, dtype=self.act_dtype)
         L.conv3x3(cur_v, self.wf(self.idx["conv3.0"][0]), g.conv3[0].bias.data, View(h3), N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_,
                   slope=G_SLOPE)
         out_nhwc = _empty(N, h, w, C_, device=dev)
         L.conv3x3(View(h3), self.wf(self.idx["conv3.2"][0]), g.conv3[2].bias.data, View(out_nhwc), N=N, H=h, W=w, OH=h, OW=w,
-                  Cin=F_, Cout=C_)
+                  Cin=F_, Cout=C_, flags=(L.CONV_OUT_F32 if h16 else 0))        # (16-bit modes: the last conv writes the fp32 image)
         if C_ == 1:
             out = out_nhwc.view(N, 1, h, w)
         else:
@@ -531,11 +565,19 @@ class GeneratorEngine:
         F_, C_ = g.filters, g.channels
         dev = g_out.device
         g_out = g_out.contiguous().float()
-        if C_ == 1:
+        h16 = self.precision in H16_DTYPE
+        if h16:
+            # 16-bit storage: the (loss-scaled) output gradient enters zero-padded to one 16-channel chunk
+            go = torch.zeros(N, h, w, 16, dtype=self.act_dtype, device=dev)
+            go[..., :C_] = g_out.permute(0, 2, 3, 1)
+            cgo = 16
+        elif C_ == 1:
             go = g_out.view(N, h, w, 1)
+            cgo = C_
         else:
             go = _empty(N, h, w, C_, device=dev)
             L.nchw_to_nhwc(g_out, View(go), N, C_, h, w)
+            cgo = C_
         grads = self._alloc_grads(dev)
         ups, h3 = saved["ups"], saved["h3"]
         fin = saved["fin"]
@@ -544,12 +586,13 @@ class GeneratorEngine:
 
         # conv3.2 (F -> C) then conv3.0 (F -> F, LeakyReLU)
         c32, c30 = g.conv3[2], g.conv3[0]
-        L.conv3x3_wgrad(View(h3), View(go), grads[c32.weight], grads[c32.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_, scale=self._grad_scale)
-        g_h3 = _empty(N, h, w, F_, device=dev)
-        L.conv3x3(View(go), self.wb(self.idx["conv3.2"][1]), None, View(g_h3), N=N, H=h, W=w, OH=h, OW=w, Cin=C_, Cout=F_,
+        L.conv3x3_wgrad(View(h3), View(go), grads[c32.weight], grads[c32.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_, scale=self._grad_scale,
+                        precision=(self._wprec() if h16 else 0))
+        g_h3 = _empty(N, h, w, F_, device=dev, dtype=self.act_dtype)
+        L.conv3x3(View(go), self.wb(self.idx["conv3.2"][1]), None, View(g_h3), N=N, H=h, W=w, OH=h, OW=w, Cin=cgo, Cout=F_,
                   mask=View(h3), mask_slope=G_SLOPE)
-        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
-        g_cur = _empty(N, h, w, F_, device=dev)
+        L.conv3x3_wgrad(pre3_v, View(g_h3), grads[c30.weight], grads[c30.bias], N=N, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, scale=self._grad_scale, precision=self._wprec())
+        g_cur = _empty(N, h, w, F_, device=dev, dtype=self.act_dtype)
         # the tensor feeding conv3.0 is a LeakyReLU output (last upsample stage) unless final RRDBs / no upsampling sit between
         mask_v = None
         if fin is None and ups:
@@ -572,8 +615,8 @@ class GeneratorEngine:
             xin = ups[u - 1] if u > 0 else saved["feat"]
             xin_v = View(xin) if xin.shape[3] == F_ else View(xin, 0, F_)
             L.conv3x3_wgrad(xin_v, View(g_cur), grads[conv.weight], grads[conv.bias], N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=F_, Cout=4 * F_,
-                            dy_mode=L.IN_UNSHUFFLE, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
-            g_prev = _empty(N, hh, ww, F_, device=dev)
+                            dy_mode=L.IN_UNSHUFFLE, scale=self._grad_scale, precision=self._wprec())
+            g_prev = _empty(N, hh, ww, F_, device=dev, dtype=self.act_dtype)
             L.conv3x3(View(g_cur), self.wb(self.idx[f"up{u}"][1]), None, View(g_prev), N=N, H=hh, W=ww, OH=hh, OW=ww, Cin=4 * F_, Cout=F_,
                       in_mode=L.IN_UNSHUFFLE, mask=(View(ups[u - 1]) if u > 0 else None), mask_slope=G_SLOPE)
             g_cur = g_prev
@@ -583,8 +626,8 @@ class GeneratorEngine:
         bufs = saved["bufs"]
         D0 = bufs[0]
         trunk_v = View(trunk) if trunk.shape[3] == F_ else View(trunk, 0, F_)
-        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_, scale=self._grad_scale, precision=({"bf16x3": 1, "bf16": 2}.get(self.precision, 0) if F_ % 8 == 0 else 0))
-        g_trunk = _empty(N, H, W, F_, device=dev)
+        L.conv3x3_wgrad(trunk_v, View(g_feat), grads[g.conv2.weight], grads[g.conv2.bias], N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_, scale=self._grad_scale, precision=self._wprec())
+        g_trunk = _empty(N, H, W, F_, device=dev, dtype=self.act_dtype)
         L.conv3x3(View(g_feat), self.wb(self.idx["conv2"][1]), None, View(g_trunk), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=F_)
         self._reduce_bucket("tail")
         if len(g.res_blocks) > 0:
@@ -594,12 +637,13 @@ class GeneratorEngine:
         g_out1 = g_out1 + g_feat                         # trunk skip (models.py:126)
         # conv1
         L.conv3x3_wgrad(View(saved["x"]), View(g_out1), grads[g.conv1.weight], grads[g.conv1.bias], N=N, H=H, W=W, OH=H, OW=W,
-                        Cin=C_, Cout=F_, scale=self._grad_scale)
+                        Cin=C_, Cout=F_, scale=self._grad_scale, precision=(self._wprec() if h16 else 0))
         self._reduce_bucket("conv1")
         dx = None
         if need_input_grad:
             dxn = _empty(N, H, W, C_, device=dev)
-            L.conv3x3(View(g_out1), self.wb(self.idx["conv1"][1]), None, View(dxn), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=C_)
+            L.conv3x3(View(g_out1), self.wb(self.idx["conv1"][1]), None, View(dxn), N=N, H=H, W=W, OH=H, OW=W, Cin=F_, Cout=C_,
+                      flags=(L.CONV_OUT_F32 if h16 else 0))
             if C_ == 1:
                 dx = dxn.view(N, 1, H, W)
             else:

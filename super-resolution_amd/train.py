@@ -43,6 +43,15 @@ class _AllReduceMean(torch.autograd.Function):
         return g / dist.get_world_size()
 
 
+def _uses(stream, *tensors):
+    """Tell the caching allocator that ``tensors`` (allocated on another stream) are read or written by work queued on ``stream``:
+    a block freed on its home stream is then not handed out again before that work has run.  Every tensor that crosses between the
+    main stream and the discriminator streams goes through here, so the schedule does not rest on the joins alone."""
+    for t in tensors:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(stream)
+
+
 class Stepper:
     def __init__(self, workload="g_only", res_blocks=23, device=None, hr=256, factor=4, distributed=False, channels=1,
                  filters=64, res_scale=0.2, lr=2e-4, betas=(0.9, 0.999), d_channels=(16, 32, 32, 64), lambdas=(0.2, 1.0),
@@ -187,6 +196,7 @@ class Stepper:
             have_gt = main.record_event()
             for k in range(2):
                 self._d_streams[k].wait_event(have_gt)
+                _uses(self._d_streams[k], ground_truth[k], ground_truth_lr[k])
                 with torch.cuda.stream(self._d_streams[k]), torch.no_grad():
                     early_real[k] = self.discriminators[k](ground_truth[k], ground_truth_lr[k])
         generated = [self.generator(imgs_lr), self.generator.srs]
@@ -201,6 +211,7 @@ class Stepper:
             D = self.discriminators[k]
             if two_streams:
                 self._d_streams[k].wait_stream(main)
+                _uses(self._d_streams[k], generated[k], generated_lr[k], ground_truth[k], ground_truth_lr[k], imgs_lr, imgs_hr)
             ctx = torch.cuda.stream(self._d_streams[k]) if two_streams else contextlib.nullcontext()
             with ctx:
                 loss_pixel = self.criterion_pixel(self._gmean(generated[k].mean(0))[None, ...], self._gmean(ground_truth[k].mean(0))[None, ...])
@@ -255,6 +266,7 @@ class Stepper:
         if two_streams:
             for k in tots:
                 main.wait_stream(self._d_streams[k])
+                _uses(main, tots[k], *parts[k].values())
         for k in sorted(tots):
             loss_G = loss_G + self.lambdas[k] * tots[k]
         return loss_G, generated, ground_truth, parts
@@ -333,6 +345,7 @@ class Stepper:
                     self._d_streams[k].wait_event(pre_backward)
                 else:
                     self._d_streams[k].wait_stream(main)
+                _uses(self._d_streams[k], ground_truth[k], generated[k], ground_truth_lr[k], *(() if epsilons is None else (epsilons[k],)))
             with (torch.cuda.stream(self._d_streams[k]) if two_streams else contextlib.nullcontext()):
                 self.optimizer_D[k].zero_grad(set_to_none=True)
                 loss_D, gp = self.d_phase_loss(k, ground_truth[k], generated[k].detach(), None if epsilons is None else epsilons[k],
@@ -340,8 +353,9 @@ class Stepper:
                 loss_D.backward()
                 losses_D[k] = loss_D
         if two_streams:
-            for k, _ in d_items:
+            for k, D in d_items:
                 main.wait_stream(self._d_streams[k])
+                _uses(main, losses_D[k], *[q.grad for q in D.parameters() if q.grad is not None])
         for k, D in d_items:
             loss_D = losses_D[k]
             self._sync_grads(D)          # (collectives stay on the main stream, in the same order on every rank)

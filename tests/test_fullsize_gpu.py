@@ -42,10 +42,21 @@ def _pack(L, w, fmt, transpose=False):
     return dst
 
 
-@pytest.mark.parametrize("fmt", [0, 1, 3, 5])      # direct fp32, split-bf16, Winograd F(2,3), Winograd F(4,3)
+@pytest.fixture(autouse=True)
+def _reset_w42_form(U):
+    yield
+    U.L.lib().srk_debug_set_wino42_nmt(0)
+
+
+# direct fp32, split-bf16, Winograd F(2,3), Winograd F(4,3), 2-D Winograd F(2x4,3x3) in its 16-row form (61: what configs[1]'s
+# launch set selects at N = 16, 64 x 64) and in its 32-row form (62: the batch-32 launch set of configs[2])
+@pytest.mark.parametrize("fmt", [0, 1, 3, 5, 61, 62])
 @pytest.mark.parametrize("ci", [64, 320])
 def test_adjoint_and_linearity_at_full_dense_block_size(U, fmt, ci):
     L = U.L
+    if fmt in (61, 62):
+        L.lib().srk_debug_set_wino42_nmt(fmt - 60)
+        fmt = 6
     g = torch.Generator(device="cuda").manual_seed(ci + fmt)
     x = torch.randn(N, H, W, 5 * F, device="cuda", generator=g)
     x2 = torch.randn(N, H, W, 5 * F, device="cuda", generator=g)

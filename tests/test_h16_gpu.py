@@ -1,0 +1,254 @@
+"""GPU parity of the 16-bit-storage kernels (wp_format 7 = fp16, 8 = bf16; BASELINE configs[4]'s reduced-precision path) against
+the CPU oracle.  The oracle runs in fp32 on the SAME 16-bit-rounded inputs and weights, so what is left is accumulation order and the
+one rounding of the 16-bit output: tolerance 2 ulp of the storage type at the output's max-abs (fp16: 2^-10, bf16: 2^-7); the fp32
+outputs (weight gradients, the last conv's fp32 image) are held to 2e-4 / 2e-3."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import esrgan_oracle as O  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+DT = {7: torch.float16, 8: torch.bfloat16}
+TOL16 = {7: 2.0 ** -10, 8: 2.0 ** -7}
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.fixture(scope="module")
+def U():
+    import srk_testutil
+    return srk_testutil
+
+
+@pytest.fixture(autouse=True)
+def _reset_form(U):
+    yield
+    U.L.lib().srk_debug_set_h16_mt(0)
+
+
+def _q(t, fmt):
+    """round to the storage type and back: what the kernel sees"""
+    return t.to(DT[fmt]).float()
+
+
+def _nhwc16(U, x_nchw, fmt, ldc=None, coff=0):
+    return U.nhwc(x_nchw, ldc, coff).to(DT[fmt]).contiguous()
+
+
+def _pack(U, w, fmt, transpose=False, ps=False, k_pad=None, scale=1.0, c_begin=0, c_len=None):
+    L = U.L
+    co, ci = w.shape[:2]
+    src = w.contiguous().cuda()
+    if transpose:
+        K, M = co, (c_len or ci)
+    else:
+        K, M = ci, co
+    Kt = k_pad or K
+    dst = torch.zeros(L.packed_floats(Kt, M, fmt), dtype=torch.float32, device="cuda")
+    t = L.PackTable(src.device, fmt)
+    t.add(src, dst, M=M, k_off=0, k_len=K, K_total=Kt, transpose=transpose, ps=ps, scale=scale, c_begin=c_begin)
+    t.run()
+    torch.cuda.synchronize()
+    return L_PW(dst, fmt)
+
+
+class L_PW:
+    def __init__(self, t, fmt):
+        self.t, self.fmt = t, fmt
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 32, 32, 2), (320, 64, 16, 32, 1), (16, 64, 9, 7, 2), (64, 128, 33, 17, 1),
+                                         (128, 64, 20, 40, 1), (16, 64, 5, 3, 1), (64, 64, 1, 1, 1), (48, 192, 16, 35, 2)])
+def test_h16_conv_fwd(U, fmt, mt, ci, co, h, w, n):
+    L = U.L
+    L.lib().srk_debug_set_h16_mt(mt)
+    x = _q(_rand((n, ci, h, w), 71), fmt)
+    wt = _q(_rand((co, ci, 3, 3), 72, 1.0 / np.sqrt(9 * ci)), fmt)
+    b = _rand((co,), 73, 0.1)
+    ref = O.lrelu(O.conv3x3(x, wt, b), 0.01)
+    wp = _pack(U, wt, fmt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(_nhwc16(U, x, fmt)), wp, b.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co, slope=0.01)
+    assert U.rel_err(U.nchw(y.float()), ref) < TOL16[fmt]
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("mt", [2, 4])
+def test_h16_slices_residuals_mask_and_dgrad(U, fmt, mt):
+    """the dense-block addressing (channel prefix in, channel slice out, two residuals, alpha, LeakyReLU' mask) and the data
+    gradient (transposed, tap-flipped weights) on the 16-bit kernels"""
+    L = U.L
+    L.lib().srk_debug_set_h16_mt(mt)
+    n, h, w, F_ = 2, 12, 37, 64
+    xfull = _q(_rand((n, 5 * F_, h, w), 74), fmt)
+    wt = _q(_rand((F_, 3 * F_, 3, 3), 75, 0.03), fmt)
+    b = _rand((F_,), 76, 0.1)
+    r1, r2, m = _q(_rand((n, F_, h, w), 77), fmt), _q(_rand((n, F_, h, w), 78), fmt), _q(_rand((n, F_, h, w), 79), fmt)
+    ref = 0.2 * O.conv3x3(xfull[:, F_:4 * F_], wt, b) + 0.5 * r1 + 1.0 * r2
+    ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
+    buf = _nhwc16(U, xfull, fmt)
+    out = torch.zeros(n, h, w, 2 * F_, device="cuda", dtype=DT[fmt])
+    wp = _pack(U, wt, fmt)
+    for aux in ("r1r2m", "r1", "m", "r1r2"):
+        kw = {}
+        refa = 0.2 * O.conv3x3(xfull[:, F_:4 * F_], wt, b)
+        if "r1" in aux:
+            kw.update(r1=L.View(_nhwc16(U, r1, fmt)), beta1=0.5); refa = refa + 0.5 * r1
+        if "r2" in aux:
+            kw.update(r2=L.View(_nhwc16(U, r2, fmt)), beta2=1.0); refa = refa + r2
+        if "m" in aux:
+            kw.update(mask=L.View(_nhwc16(U, m, fmt)), mask_slope=0.01)
+            refa = refa * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.01))
+        out.zero_()
+        L.conv3x3(L.View(buf, F_, 3 * F_), wp, b.cuda(), L.View(out, F_, F_), N=n, H=h, W=w, OH=h, OW=w, Cin=3 * F_, Cout=F_, alpha=0.2, **kw)
+        assert U.rel_err(U.nchw(out.float(), F_, F_), refa) < TOL16[fmt], aux
+        assert out[..., :F_].abs().max().item() == 0
+    # data gradient: dx = conv(dy, flip(W)^T)
+    x = _rand((n, F_, h, w), 80).requires_grad_(True)
+    w2 = _q(_rand((2 * F_, F_, 3, 3), 81, 0.03), fmt)
+    y = O.conv3x3(x, w2, None)
+    g = _q(_rand(y.shape, 82), fmt)
+    y.backward(g)
+    wpb = _pack(U, w2, fmt, transpose=True)
+    dx = torch.full((n, h, w, F_), float("nan"), device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(_nhwc16(U, g, fmt)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=2 * F_, Cout=F_)
+    assert U.rel_err(U.nchw(dx.float()), x.grad) < TOL16[fmt]
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("mt", [2, 4])
+def test_h16_pixel_shuffle_fold_and_unshuffle(U, fmt, mt):
+    L = U.L
+    L.lib().srk_debug_set_h16_mt(mt)
+    n, F_, h, w = 2, 64, 8, 12
+    x = _q(_rand((n, F_, h, w), 83), fmt).requires_grad_(True)
+    wt = _q(_rand((4 * F_, F_, 3, 3), 84, 0.04), fmt)
+    b = _rand((4 * F_,), 85, 0.1)
+    y = O.pixel_shuffle(O.lrelu(O.conv3x3(x, wt, b), 0.01), 2)
+    wp = _pack(U, wt, fmt, ps=True)
+    bp = b.view(-1, 4).t().contiguous().view(-1).cuda()
+    out = torch.full((n, 2 * h, 2 * w, F_), float("nan"), device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(_nhwc16(U, x.detach(), fmt)), wp, bp, L.View(out), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_, slope=0.01, ps_out=True)
+    assert U.rel_err(U.nchw(out.float()), y.detach()) < TOL16[fmt]
+    g = _q(_rand(y.shape, 86), fmt)
+    y2 = O.pixel_shuffle(O.conv3x3(x, wt, None), 2)
+    y2.backward(g)
+    wpb = _pack(U, wt, fmt, transpose=True, ps=True)
+    dx = torch.full((n, h, w, F_), float("nan"), device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(_nhwc16(U, g, fmt)), wpb, None, L.View(dx), N=n, H=h, W=w, OH=h, OW=w, Cin=4 * F_, Cout=F_, in_mode=L.IN_UNSHUFFLE)
+    assert U.rel_err(U.nchw(dx.float()), x.grad) < TOL16[fmt]
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+def test_h16_boundary_convs_padded_channels_and_fp32_output(U, fmt):
+    """the image-side convs of the generator in the 16-bit mode: conv1 reads the image zero-padded to 16 channels (K_total = 16),
+    conv3.2 writes the fp32 image (SRK_CONV_OUT_F32, Cout = 3) -- models.py:63,99"""
+    L = U.L
+    n, h, w, F_, C_ = 2, 19, 41, 64, 3
+    img = _q(_rand((n, C_, h, w), 91), fmt)
+    w1 = _q(_rand((F_, C_, 3, 3), 92, 0.2), fmt)
+    b1 = _rand((F_,), 93, 0.1)
+    ref = O.conv3x3(img, w1, b1)
+    x16 = _nhwc16(U, img, fmt, ldc=16)
+    y = torch.full((n, h, w, F_), float("nan"), device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(x16), _pack(U, w1, fmt, k_pad=16), b1.cuda(), L.View(y), N=n, H=h, W=w, OH=h, OW=w, Cin=16, Cout=F_)
+    assert U.rel_err(U.nchw(y.float()), ref) < TOL16[fmt]
+    feat = _q(_rand((n, F_, h, w), 94), fmt)
+    w3 = _q(_rand((C_, F_, 3, 3), 95, 0.05), fmt)
+    b3 = _rand((C_,), 96, 0.1)
+    ref3 = O.conv3x3(feat, w3, b3)
+    out = torch.full((n, h, w, C_), float("nan"), device="cuda", dtype=torch.float32)
+    L.conv3x3(L.View(_nhwc16(U, feat, fmt)), _pack(U, w3, fmt), b3.cuda(), L.View(out), N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=C_,
+              flags=L.CONV_OUT_F32)
+    assert U.rel_err(U.nchw(out), ref3) < 2e-5 * (1 if fmt == 7 else 8) + 1e-5
+
+
+def test_h16_rejects_unsupported(U):
+    L = U.L
+    x = torch.zeros(1, 8, 8, 24, device="cuda", dtype=torch.float16); y = torch.zeros(1, 8, 8, 64, device="cuda", dtype=torch.float16)
+    wp = L_PW(torch.zeros(L.packed_floats(32, 64, 7), device="cuda"), 7)
+    with pytest.raises(RuntimeError):
+        L.conv3x3(L.View(x), wp, None, L.View(y), N=1, H=8, W=8, OH=8, OW=8, Cin=24, Cout=64)      # Cin % 16
+    with pytest.raises(ValueError):
+        L.conv3x3(L.View(x.float()), wp, None, L.View(y), N=1, H=8, W=8, OH=8, OW=8, Cin=16, Cout=64)   # fp32 view with a 16-bit format
+
+
+# ---------------------------------------------------------------------------------------------------------------- weight gradient
+WPREC = {7: 3, 8: 4}
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 16, 16, 2), (128, 64, 24, 40, 1), (64, 128, 9, 7, 2), (320, 64, 8, 16, 1), (16, 64, 33, 17, 1),
+                                         (64, 16, 5, 50, 1), (40, 72, 20, 20, 1)])
+def test_h16_wgrad(U, fmt, ci, co, h, w, n):
+    """dW / db in fp32 from 16-bit x and dy (precision 3 / 4) vs autograd on the same rounded tensors: products of 16-bit values are
+    exact in fp32, so only the summation order differs"""
+    L = U.L
+    x = _q(_rand((n, ci, h, w), 101), fmt).requires_grad_(False)
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    b = torch.zeros(co, requires_grad=True)
+    dy = _q(_rand((n, co, h, w), 102), fmt)
+    O.conv3x3(x, wt, b).backward(dy)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda"); db = torch.full((co,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(_nhwc16(U, x, fmt)), L.View(_nhwc16(U, dy, fmt)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co,
+                    precision=WPREC[fmt], scale=0.5)
+    assert U.rel_err(dw.cpu(), 0.5 * wt.grad) < 2e-4
+    assert U.rel_err(db.cpu(), 0.5 * b.grad) < 2e-4
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+def test_h16_wgrad_dense_block_batch_unshuffle_and_padded_channels(U, fmt):
+    L = U.L
+    n, h, w, F_ = 2, 24, 32, 64
+    # the five convs of a dense block in ONE batched launch: conv k reads the channel prefix [0, kF), its dy is a slice of E
+    D = _q(_rand((n, 5 * F_, h, w), 111), fmt)
+    E = _q(_rand((n, 5 * F_, h, w), 112), fmt)
+    Dd, Ed = _nhwc16(U, D, fmt), _nhwc16(U, E, fmt)
+    probs, refs = [], []
+    for k in range(1, 6):
+        wt = torch.zeros(F_, k * F_, 3, 3, requires_grad=True); b = torch.zeros(F_, requires_grad=True)
+        O.conv3x3(D[:, :k * F_], wt, b).backward(E[:, (5 - k) * F_:(6 - k) * F_])
+        dw = torch.full((F_, k * F_, 3, 3), float("nan"), device="cuda"); db = torch.full((F_,), float("nan"), device="cuda")
+        probs.append(dict(x=L.View(Dd, 0, k * F_), dy=L.View(Ed, (5 - k) * F_, F_), dw=dw, db=db, Cin=k * F_, Cout=F_, scale=1.0))
+        refs.append((wt.grad, b.grad))
+    L.conv3x3_wgrad_batched(probs, N=n, H=h, W=w, OH=h, OW=w, precision=WPREC[fmt])
+    for p, (gw, gb) in zip(probs, refs):
+        assert U.rel_err(p["dw"].cpu(), gw) < 2e-4 and U.rel_err(p["db"].cpu(), gb) < 2e-4
+    # upsampling conv: dy is the gradient of the PixelShuffled output, read through SRK_IN_UNSHUFFLE
+    x = _q(_rand((n, F_, h, w), 113), fmt)
+    wt = torch.zeros(4 * F_, F_, 3, 3, requires_grad=True); b = torch.zeros(4 * F_, requires_grad=True)
+    g = _q(_rand((n, F_, 2 * h, 2 * w), 114), fmt)
+    O.pixel_shuffle(O.conv3x3(x, wt, b), 2).backward(g)
+    dw = torch.full((4 * F_, F_, 3, 3), float("nan"), device="cuda"); db = torch.full((4 * F_,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(_nhwc16(U, x, fmt)), L.View(_nhwc16(U, g, fmt)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_,
+                    dy_mode=L.IN_UNSHUFFLE, precision=WPREC[fmt])
+    assert U.rel_err(dw.cpu(), wt.grad) < 2e-4 and U.rel_err(db.cpu(), b.grad) < 2e-4
+    # image-side convs: 3 channels zero-padded to 16 on the x side (conv1) resp. the dy side (conv3.2)
+    img = _q(_rand((n, 3, h, w), 115), fmt)
+    w1 = torch.zeros(F_, 3, 3, 3, requires_grad=True); b1 = torch.zeros(F_, requires_grad=True)
+    g1 = _q(_rand((n, F_, h, w), 116), fmt)
+    O.conv3x3(img, w1, b1).backward(g1)
+    dw = torch.full((F_, 3, 3, 3), float("nan"), device="cuda"); db = torch.full((F_,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(_nhwc16(U, img, fmt, ldc=16), 0, 16), L.View(_nhwc16(U, g1, fmt)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=3, Cout=F_,
+                    precision=WPREC[fmt])
+    assert U.rel_err(dw.cpu(), w1.grad) < 2e-4 and U.rel_err(db.cpu(), b1.grad) < 2e-4
+    w3 = torch.zeros(3, F_, 3, 3, requires_grad=True); b3 = torch.zeros(3, requires_grad=True)
+    g3 = _q(_rand((n, 3, h, w), 117), fmt)
+    O.conv3x3(x, w3, b3).backward(g3)
+    dw = torch.full((3, F_, 3, 3), float("nan"), device="cuda"); db = torch.full((3,), float("nan"), device="cuda")
+    L.conv3x3_wgrad(L.View(_nhwc16(U, x, fmt)), L.View(_nhwc16(U, g3, fmt, ldc=16), 0, 16), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=3,
+                    precision=WPREC[fmt])
+    assert U.rel_err(dw.cpu(), w3.grad) < 2e-4 and U.rel_err(db.cpu(), b3.grad) < 2e-4

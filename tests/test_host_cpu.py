@@ -28,6 +28,19 @@ def test_abi_library_exports_every_declared_symbol(srk):
     assert lib.srk_packed_floats(1, 1) == 2 * 9 * 2 * 32 * 4      # K rounds up to 16 (both fragment formats share buffers)
 
 
+def test_wino42_packed_buffer_covers_the_kernels_unconditional_prefetch(srk):
+    """srk_conv_w42.hip prefetches the weights of (chunk q + 1, channel pair 0) in every chunk, also behind the last one, through
+    the scalar offset of raw buffer loads (not range-checked): byte offsets up to (2 nq + 1) * sB_ep with nq = ceil(K / 8) 8-channel
+    chunks and sB_ep = 24 positions x 2 k-halves x CoutP x 8 bytes.  The packed buffer must cover them (mapped bytes, never used)."""
+    lib = srk._lib.lib()
+    for K in (8, 16, 24, 64, 72, 128, 320):
+        for M in (64, 128, 256):
+            Mp = (M + 31) // 32 * 32
+            nq = (K + 7) // 8
+            highest = (2 * nq + 1) * 24 * 2 * Mp * 8
+            assert lib.srk_packed_floats_wino42(K, M) * 4 >= highest, (K, M)
+
+
 def test_struct_layouts_match_header(srk, tmp_path):
     """ctypes mirrors == what a C compiler makes of include/srk.h (sizes and a few offsets)."""
     import subprocess
