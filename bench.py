@@ -11,9 +11,10 @@ GeneratorRRDB(1, 64, 23, num_upsample=2)):
   g_only : the reference's warm-up iteration (esrgan.py:416-439): G forward, L1, backward, Adam, batch 16/GPU
            (BASELINE configs[1])
   c4     : BASELINE configs[4]: the same warm-up iteration on GeneratorRRDB(3, 64, 23, num_upsample=2), 3x128x128 -> 3x512x512
-           photographic-style images, batch 8/GPU, reduced-precision MFMA path.  configs[4] says fp16; this build's
-           reduced-precision kernels take bf16 operands (fp32 accumulate, fp32 master weights and activations in HBM):
-           same MFMA rate as fp16 on gfx950 (2.5 PFLOP/s dense), wider exponent, no loss scaling -- `dtype` says so.
+           photographic-style images, batch 8/GPU, fp16 path: activations and gradient buffers STORED in fp16, fp16 MFMA operands,
+           fp32 accumulate, fp32 master weights, dynamic loss scaling (--precision bf16s: the same in bf16, no loss scaling).
+The default run (gan, one GPU) appends short g_only and c4 measurements as "configs": {...} to its JSON line, so one record
+carries all three single-GPU configurations of BASELINE.json.
 Inputs are generated on the GPU before the timed region.  N > 1: ``python bench.py --gpus N`` starts its N ranks itself
 (``torch.distributed.run`` as a child process, before anything touches the GPU); under an external
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` it takes RANK / LOCAL_RANK / WORLD_SIZE as
@@ -40,7 +41,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (
 # per workload: image channels, HR extent, per-GPU batch, the Stepper's workload, default precision
 WORKLOADS = {"gan": dict(channels=1, hr=256, batch=32, step="gan", precision="f32"),
              "g_only": dict(channels=1, hr=256, batch=16, step="g_only", precision="f32"),
-             "c4": dict(channels=3, hr=512, batch=8, step="g_only", precision="bf16")}
+             "c4": dict(channels=3, hr=512, batch=8, step="g_only", precision="fp16")}
 
 
 def parse():
@@ -53,9 +54,11 @@ def parse():
                          "c4 = configs[4] (3-channel 128->512, bf16 MFMA path, batch 8)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 for g_only, 32 for gan)")
     ap.add_argument("--res-blocks", type=int, default=23)
-    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", ""), choices=["", "f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("SRK_PRECISION", ""), choices=["", "f32", "bf16x3", "bf16", "fp16", "bf16s"],
                     help="f32 (default for gan / g_only, the headline): exact-fp32 MFMA everywhere.  bf16x3: opt-in split-bf16 MFMA "
-                         "mode.  bf16 (default for c4): bf16 MFMA operands, fp32 accumulate")
+                         "mode.  fp16 (default for c4) / bf16s: 16-bit activation storage + MFMA operands, fp32 accumulate, fp32 master "
+                         "weights (fp16: with loss scaling).  bf16: bf16 operands on fp32 storage (round 2's stand-in)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the g_only / c4 sub-records of the default run")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra opt-in bf16x3 measurement and the full-size parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket conv launches with events")
@@ -149,7 +152,8 @@ def cpu_baseline(res_blocks, workload):
 def full_size_parity(sr, res_blocks, dev, workload):
     """Generator forward at the workload's full architecture (F=64, R=23, 4x) on 2 jet images (1 photographic image for c4),
     HIP path vs the CPU fp32 oracle on identical weights/inputs: max |diff| / max |ref| per precision mode, with the tolerance
-    each mode is held to (f32 / bf16x3: BASELINE's 1e-3; bf16 operands: 3e-2, the mixed-precision bar of configs[4])."""
+    each mode is held to (f32 / bf16x3: BASELINE's 1e-3; 16-bit activation storage: fp16 4e-3, bf16 3e-2 -- one rounding per stored
+    activation along 351 convolutions, the mixed-precision bar of configs[4])."""
     from oracle import esrgan_oracle as O
     wl = WORKLOADS[workload]
     ch, hr_px = wl["channels"], wl["hr"]
@@ -163,13 +167,13 @@ def full_size_parity(sr, res_blocks, dev, workload):
     gen = sr.GeneratorRRDB(ch, filters=64, num_res_blocks=res_blocks, num_upsample=2).to(dev)
     gen.load_state_dict(sd)
     out = {}
-    modes = ("f32", "bf16x3") if wl["precision"] == "f32" else ("f32", "bf16x3", "bf16")
+    modes = ("f32", "bf16x3") if wl["precision"] == "f32" else ("f32", "fp16", "bf16s")
     for mode in modes:
         gen._engine.precision = mode
         with torch.no_grad():
             y = gen(lr.to(dev)).cpu()
         out[mode] = float((y - ref).abs().max() / ref.abs().max())
-    out["tolerance"] = {"f32": 1e-3, "bf16x3": 1e-3, "bf16": 3e-2}
+    out["tolerance"] = {"f32": 1e-3, "bf16x3": 1e-3, "bf16": 3e-2, "fp16": 4e-3, "bf16s": 3e-2}
     out["ok"] = all(out[m] < out["tolerance"][m] for m in modes)
     out["what"] = ("GeneratorRRDB(%d,64,%d,num_upsample=2) forward, %s -> %s, max-abs relative error vs the CPU fp32 oracle"
                    % (ch, res_blocks, "x".join(map(str, lr.shape)), "x".join(map(str, ref.shape))))
@@ -241,39 +245,44 @@ def main():
     precision = args.precision or wl["precision"]
     hr_px, channels = wl["hr"], wl["channels"]
     batch = args.batch or wl["batch"]
-    torch.manual_seed(0)                                  # identical replicas on every rank
-    stepper = train.Stepper(workload=wl["step"], res_blocks=args.res_blocks, device=dev, hr=hr_px, factor=FACTOR, channels=channels,
-                            distributed=(world > 1 or force_dist))
-    stepper.generator._engine.precision = precision
-    lr_img, hr_img = synth_batch(batch, dev, 1234 + rank, channels, hr_px)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        stepper.step(lr_img, hr_img)
-    barrier()
-    # Per-launch HIP events bracket every conv / wgrad launch during the FIRST timed step only: bracketing all of them
-    # costs ~4.5 % of the step (measured 132.4 vs 126.5 ms), one step in K keeps the perturbation of `value` below
-    # 0.5 % while still timing >1000 launches live inside the timed region.
-    timed_probe = 0 if args.no_kernel_timing else 1
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        if it < timed_probe and it == 0:
-            L.KernelTimer.start()
-        stepper.step(lr_img, hr_img)
-        if it + 1 == timed_probe:
-            L.KernelTimer.active = False           # stop recording; elapsed times are read after the region
-    barrier()
-    dt = time.perf_counter() - t0
-    ktimes = None if args.no_kernel_timing else L.KernelTimer.stop()
+    def measure(workload, precision, batch, steps, warmup, probe):
+        """W untimed + K timed steps of one workload; returns (seconds for the K steps [max over ranks], per-kernel event times of the
+        first timed step or None, the stepper, the batch)."""
+        w = WORKLOADS[workload]
+        torch.manual_seed(0)                                  # identical replicas on every rank
+        stepper = train.Stepper(workload=w["step"], res_blocks=args.res_blocks, device=dev, hr=w["hr"], factor=FACTOR, channels=w["channels"],
+                                distributed=(world > 1 or force_dist))
+        stepper.generator._engine.precision = precision
+        lr_img, hr_img = synth_batch(batch, dev, 1234 + rank, w["channels"], w["hr"])
+        for _ in range(warmup):
+            stepper.step(lr_img, hr_img)
+        barrier()
+        # Per-launch HIP events bracket every conv / wgrad launch during the FIRST timed step only: bracketing all of them
+        # costs ~4.5 % of the step (measured 132.4 vs 126.5 ms), one step in K keeps the perturbation of `value` below
+        # 0.5 % while still timing >1000 launches live inside the timed region.
+        timed_probe = 1 if probe else 0
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if it < timed_probe and it == 0:
+                L.KernelTimer.start()
+            stepper.step(lr_img, hr_img)
+            if it + 1 == timed_probe:
+                L.KernelTimer.active = False           # stop recording; elapsed times are read after the region
+        barrier()
+        dt = time.perf_counter() - t0
+        ktimes = L.KernelTimer.stop() if probe else None
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return tmax.item(), ktimes, stepper, (lr_img, hr_img)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    dt, ktimes, stepper, (lr_img, hr_img) = measure(args.workload, precision, batch, args.steps, args.warmup, not args.no_kernel_timing)
 
     # ---- extra, outside the headline: the opt-in split-bf16 mode on the same workload (every rank takes part)
     alt = None
@@ -296,76 +305,114 @@ def main():
                "ms_per_step": adt / args.steps * 1e3}
     ms = dt / args.steps * 1e3
     value = world * batch * hr_px * hr_px * args.steps / dt
+    del stepper, lr_img, hr_img
+    torch.cuda.empty_cache()
+
+    def roofline_of(ktimes, step_ms):
+        if not ktimes:
+            return None
+        dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"])
+        name, st = dom
+        ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
+        peak_tflops = BF16_MFMA_PEAK_TFLOPS if ("bf16" in name or "h16" in name) else F32_MFMA_PEAK_TFLOPS
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:   # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                # same command (tools/traffic_from_pmc.py; FETCH_SIZE x2 on gfx950), not collectable in-process
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command on an earlier box (PMC counters cannot be read in-process); not measured in this run")
+            except Exception:
+                traffic = None
+        # `frac` is the fraction of the matrix pipe's peak that the kernel SUSTAINS: executed multiply-adds / time / peak.
+        # The Winograd kernels execute fewer multiply-adds than the convolution's algorithmic count -- F(2,3) along W:
+        # 4 instead of 6 per output pair (2/3); F(4,3): 6 instead of 12 per output quad (1/2) -- so the algorithmic-equivalent
+        # rate (what a direct kernel would need to match the time) is reported beside it and may exceed the peak.
+        # F(2x4,3x3) (wino42): 24 instead of 72 per 2x4 output patch (1/3)
+        if "wino42" in name:
+            fac, what = 1.0 / 3.0, "2-D Winograd F(2x4, 3x3): F(4,3) along W times F(2,3) along H"
+        elif "wino22" in name:
+            fac, what = 4.0 / 9.0, "2-D transposed Winograd F(2,3) x F(2,3)"
+        else:
+            fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
+        if "bf16x3" in name:      # template argument TERMS: 3 bf16 MFMAs per product (split operands) or 1 (plain bf16 operands)
+            terms = 3 if name.rstrip(">+reduce").rstrip(">").endswith("3") else 1
+            fac, what = float(terms), ("direct, %d bf16 MFMA%s per product, fp32 accumulate" % (terms, "s" if terms > 1 else ""))
+        if "h16" in name:
+            what = "direct, 16-bit activation storage, %s MFMA operands, fp32 accumulate" % ("fp16" if "_Float16" in name else "bf16")
+        return {"bound": "mfma", "kernel": name, "achieved": round(ach * fac, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(ach * fac / peak_tflops, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
+                "avg_gflop_per_launch": round(st["flops"] / st["n"] / 1e9, 3),
+                "algorithm": what, "executed_over_algorithmic": round(fac, 4),
+                "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak_tflops, 4),
+                "probe": "HIP events around every conv/wgrad launch of the first timed step, on the launching stream",
+                # Sum of the bracketed launches of the PROBED step over the AVERAGE step: the probed step runs without stream overlap and
+                # with event overhead, so this can exceed 1 -- it is not the conv share of an average step
+                "probed_step_conv_ms_over_avg_step_ms": round(sum(v["ms"] for v in ktimes.values()) / step_ms, 4),
+                "by_kernel": {k: {"launches": v["n"], "ms": round(v["ms"], 3),
+                                  "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                              for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])[:(40 if L.KernelTimer.detail else 6)]}}
+
+    DTYPES = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate)",
+              "bf16": "bf16 (MFMA operands; fp32 accumulate, fp32 master weights and fp32 activations in HBM)",
+              "fp16": "fp16 (activations and gradient buffers stored in fp16, fp16 MFMA operands; fp32 accumulate, fp32 master weights, "
+                      "dynamic loss scaling)",
+              "bf16s": "bf16 (activations and gradient buffers stored in bf16, bf16 MFMA operands; fp32 accumulate, fp32 master weights)"}
+
+    def config_of(workload, batch):
+        w = WORKLOADS[workload]
+        ch, hp = w["channels"], w["hr"]
+        return {"workload": f"{workload}: GeneratorRRDB({ch},64,{args.res_blocks},num_upsample=2) "
+                            f"{hp // FACTOR}x{hp // FACTOR}->{hp}x{hp}, "
+                            f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
+                                                    if w["step"] == "gan" else ", L1 + Adam"),
+                "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
+                "generator_train_gflop_per_image": 971.4 if ch == 1 else 3887.6,
+                "inputs": "the same synthetic batch every step (resident in HBM); tools/soak.py with a fresh batch per "
+                          "iteration measures the same ms/iter, and the d_threshold gate stays open on it"}
+
+    STEP_NAMES = {"gan": "G+D step", "g_only": "G-only warm-up step", "c4": "G-only warm-up step, configs[4]"}
+
+    # ---- the other single-GPU configurations of BASELINE.json beside the headline (default run only): short measurements AFTER the
+    # headline's timed region, each with its own roofline leg, so that one driver-run record carries configs[1], [2] and [4]
+    subs = None
+    if args.workload == "gan" and world == 1 and not args.no_configs and not args.precision and not args.batch:
+        subs = {}
+        for sub in ("g_only", "c4"):
+            w = WORKLOADS[sub]
+            ssteps = max(3, min(args.steps, 8))
+            sdt, skt, sst, sbatch = measure(sub, w["precision"], w["batch"], ssteps, 2, not args.no_kernel_timing)
+            del sst, sbatch
+            torch.cuda.empty_cache()
+            sms = sdt / ssteps * 1e3
+            subs[sub] = {"metric": f"HR-pixels/s + ms/iter ({STEP_NAMES[sub]})", "value": w["batch"] * w["hr"] * w["hr"] * ssteps / sdt,
+                         "unit": "HR-px/s", "ms_per_step": sms, "steps": ssteps, "warmup": 2, "dtype": DTYPES[w["precision"]],
+                         "config": config_of(sub, w["batch"]), "roofline": roofline_of(skt, sms)}
 
     if rank == 0:
-        roof = None
-        if ktimes:
-            dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"])
-            name, st = dom
-            ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
-            peak_tflops = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
-            traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:   # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-                    # same command (tools/traffic_from_pmc.py; FETCH_SIZE x2 on gfx950), not collectable in-process
-                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
-                    if traffic is not None:
-                        traffic_source = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command on an earlier box (PMC counters cannot be read in-process); not measured in this run")
-                except Exception:
-                    traffic = None
-            # `frac` is the fraction of the fp32 matrix pipe's peak that the kernel SUSTAINS: executed multiply-adds / time / peak.
-            # The Winograd kernels execute fewer multiply-adds than the convolution's algorithmic count -- F(2,3) along W:
-            # 4 instead of 6 per output pair (2/3); F(4,3): 6 instead of 12 per output quad (1/2) -- so the algorithmic-equivalent
-            # rate (what a direct kernel would need to match the time) is reported beside it and may exceed the peak.
-            # F(2x4,3x3) (wino42): 24 instead of 72 per 2x4 output patch (1/3)
-            if "wino42" in name:
-                fac, what = 1.0 / 3.0, "2-D Winograd F(2x4, 3x3): F(4,3) along W times F(2,3) along H"
-            else:
-                fac, what = (0.5, "Winograd F(4,3) along W") if "wino4" in name else ((2.0 / 3.0, "Winograd F(2,3) along W") if "wino" in name else (1.0, "direct"))
-            if "bf16x3" in name:      # template argument TERMS: 3 bf16 MFMAs per product (split operands) or 1 (plain bf16 operands)
-                terms = 3 if name.rstrip(">+reduce").rstrip(">").endswith("3") else 1
-                fac, what = float(terms), ("direct, %d bf16 MFMA%s per product, fp32 accumulate" % (terms, "s" if terms > 1 else ""))
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach * fac, 2), "peak": peak_tflops, "unit": "TFLOP/s",
-                    "frac": round(ach * fac / peak_tflops, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "launches": st["n"], "avg_us": round(st["ms"] * 1e3 / st["n"], 2),
-                    "avg_gflop_per_launch": round(st["flops"] / st["n"] / 1e9, 3),
-                    "algorithm": what, "executed_over_algorithmic": round(fac, 4),
-                    "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak_tflops, 4),
-                    "probe": "HIP events around every conv/wgrad launch of the first timed step, on the launching stream",
-                    # Sum of the bracketed launches of the PROBED step over the AVERAGE step: the probed step runs without stream overlap and
-                    # with event overhead, so this can exceed 1 -- it is not the conv share of an average step
-                    "probed_step_conv_ms_over_avg_step_ms": round(sum(v["ms"] for v in ktimes.values()) / (dt / args.steps * 1e3), 4),
-                    "by_kernel": {k: {"launches": v["n"], "ms": round(v["ms"], 3),
-                                      "algorithmic_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                  for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])[:(40 if L.KernelTimer.detail else 6)]}}
+        roof = roofline_of(ktimes, ms)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args.res_blocks, args.workload)
         parity = None
         if not args.no_alt and world == 1:
             parity = full_size_parity(sr, args.res_blocks, dev, args.workload)
-        step_name = {"gan": "G+D step", "g_only": "G-only warm-up step", "c4": "G-only warm-up step, configs[4]"}[args.workload]
+            if subs is not None:
+                subs["c4"]["full_size_parity"] = full_size_parity(sr, args.res_blocks, dev, "c4")
         img = "64->256 jet images" if channels == 1 else "3-channel 128->512 images"
-        dtype = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate)",
-                 "bf16": "bf16 (MFMA operands; fp32 accumulate, fp32 master weights and activations) -- stands in for configs[4]'s fp16: "
-                         "same MFMA rate on gfx950, no loss scaling needed"}[precision]
         out = {
-            "metric": f"HR-pixels/s + ms/iter ({step_name}), {img}",
+            "metric": f"HR-pixels/s + ms/iter ({STEP_NAMES[args.workload]}), {img}",
             "value": value, "unit": "HR-px/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: GeneratorRRDB({channels},64,{args.res_blocks},num_upsample=2) "
-                                   f"{hr_px // FACTOR}x{hr_px // FACTOR}->{hr_px}x{hr_px}, "
-                                   f"batch {batch}/GPU" + (", 2x Markovian_Discriminator[16,32,32,64], relativistic BCE + GP"
-                                                           if wl["step"] == "gan" else ", L1 + Adam"),
-                       "global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}",
-                       "generator_train_gflop_per_image": 971.4 if channels == 1 else 3887.6,
-                       "inputs": "the same synthetic batch every step (resident in HBM); tools/soak.py with a fresh batch per "
-                                 "iteration measures the same ms/iter, and the d_threshold gate stays open on it"},
+            "dtype": DTYPES[precision], "data": "synthetic",
+            "config": config_of(args.workload, batch),
             "roofline": roof, "cpu_baseline": cpu, "split_bf16_mode": alt, "full_size_parity": parity,
         }
+        if subs is not None:
+            out["configs"] = subs
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -88,7 +88,7 @@ typedef struct srk_conv_args {
                                   times F(2,3) along H), 32x16 workgroup tiles, one wave per SIMD; same contract as 5
                                7 / 8: 16-BIT ACTIVATION STORAGE, fp16 (7) / bf16 (8) MFMA operands, fp32 accumulate (BASELINE configs[4]):
                                   x, y, r1, r2, mask point to 16-bit elements (ldc / coff in elements, multiples of 8), bias stays fp32,
-                                  wp = fragments of srk_pack_entry.fmt 7 / 8; stride 1, Cin % 16 == 0, Cout % 8 == 0, plain / unshuffle
+                                  wp = fragments of srk_pack_entry.fmt 7 / 8; stride 1, Cin % 32 == 0, Cout % 8 == 0, plain / unshuffle
                                   input, in_slope == 1 */
   int32_t flags;            /* SRK_CONV_OUT_F32: (wp_format 7 / 8 only) y is fp32 [.., y_ldc] (y_ldc / y_coff in fp32 elements, any Cout);
                                excludes r1 / r2 / mask / ps_out -- the generator's last conv writes the fp32 image */
@@ -176,7 +176,8 @@ typedef struct srk_pack_entry {
                                with u = G w folded in (srk_pack_weights; 4/3 the size);  5: F(4,3) fragments [K/8][3 rows x 6 pos][h][Mp][4] (twice the
                                size);  6: F(2x4, 3x3) fragments [K/8][2 channel pairs][4 row x 6 column positions][h][Mp][2] (8/3
                                the size);  7 / 8: fp16 / bf16 fragments [K/16][tap][h][Mp64][8] of 16-bit elements, Mp64 = M rounded up
-                               to 64 (k_off % 16 == 0; transpose 0 / 1).  One table = one format. */
+                               to 64 (k_off % 16 == 0; transpose 0 / 1; 16-channel chunks of dst that no entry covers -- K_total padded to the
+                               conv kernel's 32-channel stages -- are not written: the caller zeroes dst once).  One table = one format. */
   int64_t elem_begin;       /* prefix sum of work items, filled by srk_pack_plan */
 } srk_pack_entry;
 

@@ -31,6 +31,13 @@ typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifdef SRK_STAMP       // diagnostic build only (make stamp; tools/stamp_h16.py): phase stamps of wave 0 of every workgroup
+__device__ unsigned long long* g_h16_stamps = nullptr;
+#define H16_STAMP(k) do { if (threadIdx.x == 0 && g_h16_stamps) { g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define H16_STAMP(k) do { } while (0)
+#endif
+
 template <typename T> struct H16;
 template <> struct H16<_Float16> {
   typedef h16_f16x8 v8;
@@ -51,13 +58,20 @@ __device__ __forceinline__ void h16_dma(__amdgpu_buffer_rsrc_t rs, float4* dst, 
 constexpr int HW_TW = 32, HW_IW = HW_TW + 2;       // tile width / halo width
 constexpr unsigned H_OOB = 0x80000000u;
 
+// A stage = 32 input channels.  LDS image of its halo: PIXEL-major, 64 bytes per halo pixel = four 16-byte slots, slot j of pixel p
+// holds the 8-channel group g = j ^ ((p >> 2) & 3).  Pixel-major so that four consecutive DMA lanes fetch 64 contiguous bytes of one
+// pixel (a k-group-major image makes every lane of a piece touch its own cache line: 64 lines per instruction instead of 16); the
+// XOR so that the A-fragment read (32 consecutive pixels, one group per lane half) is conflict-free: over any 16 consecutive
+// pixels (4 (p & 3) + slot) mod 16 takes every value once.  A fragment's byte address: 64 p + 16 ((2 kk + hl) ^ ((p >> 2) & 3)), i.e.
+// the second k-step of the stage is the first one's address XOR 32.
 template <int MT> struct HGeo {
   static constexpr int TH = 4 * MT, IH = TH + 2, NHP = IH * HW_IW;        // halo pixels (612 / 340)
-  static constexpr int HPIECES = (2 * NHP + 63) / 64;                    // 1-KB DMA pieces of the two halo planes (20 / 11)
-  static constexpr int WPIECES = 18;                                      // [tap][k-half] x 64 couts x 16 B
-  static constexpr int STAGE4 = (HPIECES + WPIECES) * 64;                 // 16-byte slots per stage
+  static constexpr int HPIECES = (4 * NHP + 63) / 64;                    // 1-KB DMA pieces (16 pixels each) of the halo (39 / 22)
+  static constexpr int WPIECES = 36;                                      // [k-step][tap][k-half] x 64 couts x 16 B
+  static constexpr int STAGE4 = (HPIECES + WPIECES + 1) * 64;             // 16-byte slots per stage (+ one dummy piece, below)
   static constexpr int WBASE = HPIECES * 64;
-  static constexpr int NJH = (HPIECES + 3) / 4, NJW = (WPIECES + 3) / 4;  // pieces per wave (upper bounds)
+  static constexpr int DUMMY = (HPIECES + WPIECES) * 64;                  // where the zeros of a piece that does not exist land
+  static constexpr int NJH = (HPIECES + 3) / 4, NJW = WPIECES / 4;        // pieces per wave (10 / 6 halo, 9 weight)
 };
 
 // ------------------------------------------------------------------------------------------------------------------ epilogue
@@ -204,7 +218,7 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 
 // ------------------------------------------------------------------------------------------------------------------ kernel
 template <typename T, int MODE, int MT, bool OUTF32>
-__global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args a) {
+__global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a) {
   typedef typename H16<T>::v8 v8;
   typedef HGeo<MT> G;
   constexpr int SMEM4 = 2 * G::STAGE4 > 2048 ? 2 * G::STAGE4 : 2048;       // >= 4 x 8 KB of epilogue scratch
@@ -224,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args
   const int n = bid;
   const int oh0 = ty * G::TH, ow0 = tx * HW_TW, n0 = blockIdx.y * 64;
   const int CoutP = (a.Cout + 63) & ~63;
-  const int nq = a.Cin >> 4;
+  const int nq = a.Cin >> 5;                          // stages of 32 input channels
+  H16_STAMP(0);
 
   // ---- DMA plan
   const T* xbase = reinterpret_cast<const T*>(a.x);
@@ -233,127 +248,140 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args
   if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
   const T* ximg = xbase + (long)n * img_elems;
   const unsigned xbytes = (unsigned)(img_elems * 2);
-  const unsigned wbytes = (unsigned)((long)nq * 18 * CoutP * 16);
-  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, xbytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
   unsigned xvo[G::NJH];
   {
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
     for (int j = 0; j < G::NJH; ++j) {
-      const int slot = (wv + 4 * j) * 64 + lane;
-      const int h = slot >= G::NHP ? 1 : 0, hp = slot - h * G::NHP;
+      const int hp = (wv + 4 * j) * 16 + (lane >> 2);                   // halo pixel of this lane in piece wv + 4 j
+      const int g = (lane & 3) ^ ((hp >> 2) & 3);                       // the 8-channel group its slot holds
       const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
       const int ih = ih0 + hy, iw = iw0 + hx;
       unsigned v = H_OOB;
-      if (slot < 2 * G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
+      if (hp < G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
         long off;
-        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * h;
-        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * h;
+        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * g;
+        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * g;
         v = (unsigned)(off * 2);
       }
       xvo[j] = v;
     }
   }
   const unsigned wvo = (unsigned)((n0 + lane) * 16);
-  // One DMA piece (1 KB: 16 bytes per lane) of chunk q into buffer b.  Piece j < NJH: halo piece wv + 4 j; else weight piece
-  // (tap, k-half) = wv + 4 (j - NJH).  A piece that does not exist (past the last chunk; the waves' uneven shares) goes through a
-  // descriptor of ZERO records: nothing is read, zeros land in a slot nobody reads -- a scalar select, no branch in the main loop.
+  // One DMA piece (1 KB: 16 bytes per lane) of stage q into buffer b.  Piece j < NJH: halo piece wv + 4 j (halo first: it comes from
+  // HBM, the weights from L2); else weight piece (k-step, tap, k-half) = wv + 4 (j - NJH), which is contiguous in the packed
+  // weights.  A piece that does not exist (past the last stage; the waves' uneven halo shares) goes through a descriptor of ZERO
+  // records: nothing is read, and the zeros an out-of-range DMA still writes land in the stage's DUMMY piece, which nobody reads --
+  // scalar selects, no branch in the main loop.
   constexpr int NPIECE = G::NJH + G::NJW;
   auto piece = [&](int q, auto bc, auto jc) {
     constexpr int b = decltype(bc)::value, j = decltype(jc)::value;
     float4* dst = smem + b * G::STAGE4;
     if constexpr (j < G::NJH) {
-      unsigned xso = (unsigned)(16 * q * 2);
+      unsigned xso = (unsigned)(32 * q * 2);
       if (MODE == SRK_IN_UNSHUFFLE) {
-        const int c16 = 16 * q;
-        const int ij = c16 / Cps_in, c = c16 - ij * Cps_in;
+        const int c32 = 32 * q;
+        const int ij = c32 / Cps_in, c = c32 - ij * Cps_in;
         xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
       }
       const int i = wv + 4 * j;
       const bool live = q < nq && i < G::HPIECES;            // (with zero records every lane is out of range whatever the offsets)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, live ? xbytes : 0u, 0x00020000);
-      h16_dma(rs, dst + (i < G::HPIECES ? i : 0) * 64, xvo[j], xso);
+      h16_dma(rs, dst + (i < G::HPIECES ? i * 64 : G::DUMMY), xvo[j], xso);
     } else {
       const int w = wv + 4 * (j - G::NJH);
-      const bool live = q < nq && w < G::WPIECES;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, live ? wbytes : 0u, 0x00020000);
-      h16_dma(rs, dst + G::WBASE + (w < G::WPIECES ? w : 0) * 64, wvo, (unsigned)((q * 18 + w) * CoutP * 16));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, q < nq ? wbytes : 0u, 0x00020000);
+      h16_dma(rs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
     }
   };
 
   f32x16 acc[MT][2];
-  const int a_lane = hl * G::NHP + (MT * wv) * HW_IW + l32;      // + ri * IW + s
-  const int b_lane = G::WBASE + hl * 64 + l32;                    // + (tap * 2) * 64 + 32 t
+  // ---- fragment addresses (bytes from smem).  A: halo pixel p = (MT wv + ri) * 34 + l32 + s of the (ri, s) this step reads, k-step 0;
+  // k-step 1 = the same XOR 32; the other buffer = + STAGE bytes.  B: [k-step][tap][k-half][64 couts] 16-byte slots behind the halo.
+  constexpr int SPS = MT + 2, STEPS1 = 3 * SPS, STEPS = 2 * STEPS1;
+  int aaddr[STEPS1];
+#pragma unroll
+  for (int i = 0; i < STEPS1; ++i) {
+    const int s = i / SPS, ri = i % SPS;
+    const int hp = (MT * wv + ri) * HW_IW + l32 + s;
+    aaddr[i] = hp * 64 + ((hl ^ ((hp >> 2) & 1)) + 2 * ((hp >> 3) & 1)) * 16;
+  }
+  const int baddr = (G::WBASE + hl * 64 + l32) * 16;            // + ((kk * 18 + tap * 2) * 64 + 32 t) * 16
 
-  // ---- main loop.  A chunk is STEPS = 3 (MT + 2) steps L = (MT + 2) s + ri: one A fragment (halo row ri, column shift s) feeds the
-  // kernel rows r with output row m = ri - r in range, both channel halves: 2 / 4 / 6 MFMAs.  Fragments are read AHEAD, by hand:
-  //   A(L + 2) at step L into a ring of four registers sets;  the six B fragments of shift s + 1 during steps ri = 1..3 of shift s
-  //   into the other of two sets;  the DMA pieces of the next chunk one per step.
-  // The last two steps of a chunk are issued BEHIND the chunk barrier and the first reads of the next chunk, so that the matrix pipe
-  // has work while those reads are in flight (with one workgroup per CU nothing else would cover them).  Everything is straight-line
-  // code (sched_barrier between the slots); two chunks per loop iteration make ring / set / buffer indices compile-time constants.
-  constexpr int SPS = MT + 2, STEPS = 3 * SPS;
-  constexpr int RINGP = (STEPS & 3);                   // ring offset of the odd chunk of a pair (18 steps: 2; 12 steps: 0)
+  // ---- main loop.  A stage is STEPS = 2 x 3 (MT + 2) steps L: k-step kk, column shift s, halo row ri; one A fragment feeds the kernel
+  // rows r with output row m = ri - r in range, both channel halves: 2 / 4 / 6 MFMAs.  Fragments are read AHEAD, by hand:
+  //   A(L + 2) at step L into a ring of four register sets;  the six B fragments of the next (k-step, shift) group during steps
+  //   ri = 1..3 of the current one into the other of two sets;  the DMA pieces of the next stage one per step, halo first.
+  // The last two steps of a stage are issued BEHIND the stage barrier and the first reads of the next stage, so that the matrix
+  // pipe has work while those reads are in flight (one workgroup per CU: nothing else would cover them).  Straight-line code
+  // (sched_barrier between the slots); two stages per loop iteration make the buffer a compile-time constant.
   v8 Af[4], Bf[2][3][2];
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  auto rdA = [&](const float4* sb, int L) { return __builtin_bit_cast(v8, sb[a_lane + (L % SPS) * HW_IW + (L / SPS)]); };
-  auto rdB = [&](const float4* sb, int r, int s, int t) { return __builtin_bit_cast(v8, sb[b_lane + ((3 * r + s) * 2) * 64 + 32 * t]); };
-  auto mfma_step = [&](auto pc, auto lc) {
-    constexpr int P = decltype(pc)::value, L = decltype(lc)::value;
-    constexpr int s = L / SPS, ri = L % SPS;
+  const char* sm = reinterpret_cast<const char*>(smem);
+  auto rdA = [&](int P, int L) {         // (P, L are constants after unrolling)
+    const int i = L % STEPS1, kk = L / STEPS1;
+    return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + P * (G::STAGE4 * 16) + (kk ? (aaddr[i] ^ 32) : aaddr[i])));
+  };
+  auto rdB = [&](int P, int S, int r, int t) {      // S = 3 kk + s: the (k-step, shift) group
+    const int kk = S / 3, s = S % 3;
+    return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + P * (G::STAGE4 * 16) + baddr + ((kk * 18 + (3 * r + s) * 2) * 64 + 32 * t) * 16));
+  };
+  auto mfma_step = [&](auto lc) {
+    constexpr int L = decltype(lc)::value;
+    constexpr int S = L / SPS, ri = L % SPS;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int m = ri - r;
       if (m >= 0 && m < MT) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[(RINGP * P + L) & 3], Bf[(P + s) & 1][r][t], acc[m][t]);
+        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[L & 3], Bf[S & 1][r][t], acc[m][t]);
       }
     }
   };
-  auto head = [&](auto pc) {          // first fragments of a chunk of parity P: the six B fragments of shift 0, A(0), A(1)
+  auto head = [&](auto pc) {          // first fragments of the stage in buffer P: the six B fragments of group 0, A(0), A(1)
     constexpr int P = decltype(pc)::value;
-    const float4* sb = smem + P * G::STAGE4;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) Bf[P & 1][r][t] = rdB(sb, r, 0, t);
-    Af[(RINGP * P + 0) & 3] = rdA(sb, 0);
-    Af[(RINGP * P + 1) & 3] = rdA(sb, 1);
+      for (int t = 0; t < 2; ++t) Bf[0][r][t] = rdB(P, 0, r, t);
+    Af[0] = rdA(P, 0);
+    Af[1] = rdA(P, 1);
   };
-  auto chunk = [&](int q, auto pc) {
+  auto stage_fn = [&](int q, auto pc) {
     constexpr int P = decltype(pc)::value;
     using Pc = std::integral_constant<int, P>; using Pn = std::integral_constant<int, P ^ 1>;
-    const float4* sb = smem + P * G::STAGE4;
     auto step = [&](auto lc) {
       constexpr int L = decltype(lc)::value;
-      constexpr int s = L / SPS, ri = L % SPS;
-      Af[(RINGP * P + L + 2) & 3] = rdA(sb, L + 2);
-      if constexpr (ri >= 1 && ri <= 3 && s < 2) {
+      constexpr int S = L / SPS, ri = L % SPS;
+      Af[(L + 2) & 3] = rdA(P, L + 2);
+      if constexpr (ri >= 1 && ri <= 3 && S < 5) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) Bf[(P + s + 1) & 1][ri - 1][t] = rdB(sb, ri - 1, s + 1, t);
+        for (int t = 0; t < 2; ++t) Bf[(S + 1) & 1][ri - 1][t] = rdB(P, S + 1, ri - 1, t);
       }
       if constexpr (L + 2 < NPIECE) piece(q + 1, Pn{}, std::integral_constant<int, (L + 2 < NPIECE ? L + 2 : 0)>{});
       __builtin_amdgcn_sched_barrier(0);
-      mfma_step(Pc{}, lc);
+      mfma_step(lc);
       __builtin_amdgcn_sched_barrier(0);
     };
     [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - 2>{});
-    // every piece of chunk q + 1 has landed (mine: vmcnt; the others': behind the barrier) and every read of this chunk's buffer has
-    // returned (the DMA of chunk q + 2 may overwrite it)
+    // every piece of stage q + 1 has landed (mine: vmcnt; the others': behind the barrier) and every read of this stage's buffer has
+    // returned (the DMA of stage q + 2 may overwrite it)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     head(Pn{});
     piece(q + 2, Pc{}, I0{});
     piece(q + 2, Pc{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(Pc{}, std::integral_constant<int, STEPS - 2>{});
-    mfma_step(Pc{}, std::integral_constant<int, STEPS - 1>{});
+    mfma_step(std::integral_constant<int, STEPS - 2>{});
+    mfma_step(std::integral_constant<int, STEPS - 1>{});
     __builtin_amdgcn_sched_barrier(0);
   };
+  static_assert(NPIECE <= STEPS - 2 && (STEPS & 3) == 0, "one DMA piece per step; the A ring must close over a stage");
 
   [&]<int... Js>(std::integer_sequence<int, Js...>) { (piece(0, I0{}, std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, NPIECE>{});
-  __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunk is in flight
+  H16_STAMP(1);
+  __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first stage is in flight
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -363,18 +391,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  H16_STAMP(2);
   head(I0{});
   piece(1, I1{}, I0{});
   piece(1, I1{}, I1{});
   {
     int q = 0;
     for (; q + 1 < nq; q += 2) {
-      chunk(q, I0{});
-      chunk(q + 1, I1{});
+      stage_fn(q, I0{});
+      stage_fn(q + 1, I1{});
     }
-    if (q < nq) chunk(q, I0{});
+    if (q < nq) stage_fn(q, I0{});
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (empty) pieces and the reads of a chunk that does not exist
+  H16_STAMP(3);
   __builtin_amdgcn_s_barrier();          // the epilogue reuses the staging buffers
   float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
   const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
@@ -386,6 +416,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const srk_conv_args
     else if (n_aux == 2) h16_epilogue<T, MT, 2, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
     else h16_epilogue<T, MT, 3, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
   }
+  H16_STAMP(4);
+#ifdef SRK_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  H16_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ weight packing (formats 7 / 8)
@@ -459,22 +494,28 @@ int launch_h16_any(const srk_conv_args& a, int mt, hipStream_t st) {
 
 }  // namespace
 
+#ifdef SRK_STAMP
+extern "C" int srk_debug_set_h16_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_h16_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#endif
+
 extern "C" int srk_debug_set_h16_mt(int mt) { g_h16_mt = (mt == 2 || mt == 4) ? mt : 0; return SRK_OK; }
 
-// Rows per wave: 16-row tiles (MT = 4: fewer halo rows and weight reads per MFMA) when they still give every CU two workgroups,
-// else 8-row tiles.  SRK_H16_MT = 2 | 4 / srk_debug_set_h16_mt force one (A/B measurements, tests).
+// Rows per wave: 16-row tiles (MT = 4: fewer halo rows, weight reads and barriers per MFMA; one workgroup per CU either way) when
+// they fill the chip (>= 200 workgroups), else 8-row tiles.  SRK_H16_MT = 2 | 4 / srk_debug_set_h16_mt force one (A/B, tests).
 int srk_conv_h16_mt(const srk_conv_args& a) {
   if (g_h16_mt < 0) { const char* e = getenv("SRK_H16_MT"); g_h16_mt = e ? atoi(e) : 0; }
   if (g_h16_mt == 2 || g_h16_mt == 4) return g_h16_mt;
   const long wg16 = (long)a.N * srk_div_up(a.OH, 16) * srk_div_up(a.OW, HW_TW) * (srk_round_up(a.Cout, 64) / 64);
-  return wg16 >= 512 ? 4 : 2;
+  return wg16 >= 200 ? 4 : 2;
 }
 
 int srk_conv_h16_check(const srk_conv_args& a) {
   if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
-  if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cin % 16) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+  if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cin % 32) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
   if (a.OH != a.H || a.OW != a.W) return SRK_ERR_BAD_ARG;
-  if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 16))) return SRK_ERR_UNSUPPORTED;
+  if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 32))) return SRK_ERR_UNSUPPORTED;
   if ((a.x_ldc % 8) || (a.x_coff % 8) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
   const bool f32o = a.flags & SRK_CONV_OUT_F32;
   if (f32o) {

@@ -980,6 +980,7 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (wino22_env < 0) { const char* e = getenv("SRK_WGRAD_WINO22"); wino22_env = e ? atoi(e) : 1; }
   if (B.wino && wino22_env) { B.wino = 2; TH = W22_TH; }
   const bool h16 = a0.precision == 3 || a0.precision == 4;        // 16-bit storage (srk_wgrad_h16.hip): 8-row tiles
+  B.h16 = h16 ? 1 : 0;
   if (h16) TH = W16_TH;
   B.tilesW = srk_div_up(a0.OW, WTW);
   B.tilesH = srk_div_up(a0.OH, TH);
@@ -1006,7 +1007,7 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   return SRK_OK;
 }
 
-bool use_c1(const WBatch& B) { return B.n_prob == 1 && B.prob[0].Cin == 1 && B.dy_mode == SRK_IN_PLAIN; }
+bool use_c1(const WBatch& B) { return B.n_prob == 1 && B.prob[0].Cin == 1 && B.dy_mode == SRK_IN_PLAIN && !B.h16; }
 
 // number of first-stage slices of the partial-block reduction (0 = single stage)
 int reduce_slices(const WBatch& B) {

@@ -25,6 +25,7 @@ struct WProb {
 struct WBatch {
   int N, H, W, OH, OW;
   int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode, wino;
+  int h16;                  // x / dy are 16-bit tensors (srk_wgrad_args.precision 3 / 4): srk_wgrad_h16.hip only
   WProb prob[MAX_PROB];
   unsigned char c_prob[MAX_CHUNK], c_cy[MAX_CHUNK], c_cz[MAX_CHUNK];
 };

@@ -215,14 +215,14 @@ class GeneratorEngine:
         self.fmt_f, self.fmt_b = {}, {}      # flat index -> fragment format of that packed conv
         jobs_f, jobs_b = [], []   # deferred (need materialized dst)
         bf = self.precision in ("bf16x3", "bf16")
-        h16 = self.precision in H16_DTYPE          # 16-bit storage: ONE format for every conv, image-side channels zero-padded to 16
+        h16 = self.precision in H16_DTYPE          # 16-bit storage: ONE format for every conv, image-side channels zero-padded to 32
         hfmt = L.FMT_OF_DTYPE[H16_DTYPE[self.precision]] if h16 else 0
-        if h16 and F_ % 16 != 0:
-            raise NotImplementedError("the 16-bit-storage modes need filters % 16 == 0")
+        if h16 and F_ % 32 != 0:
+            raise NotImplementedError("the 16-bit-storage modes need filters % 32 == 0")
         self._built_precision = self.precision
 
         def kpad(k):
-            return (k + 15) // 16 * 16 if h16 else k
+            return (k + 31) // 32 * 32 if h16 else k       # the 16-bit conv kernel stages 32 input channels at a time
 
         # exact-fp32 mode: stride-1 convs with 64-multiple outputs run the Winograd F(2,3)-along-W kernel (2/3 of the MFMAs)
         wino = (not bf) and os.environ.get("SRK_WINOGRAD", "1") != "0"
@@ -495,8 +495,8 @@ class GeneratorEngine:
         h16 = self.precision in H16_DTYPE
         cin1 = C_
         if h16:
-            # 16-bit storage: the image enters zero-padded to one 16-channel chunk (conv1's packed weights are padded alike)
-            cin1 = 16
+            # 16-bit storage: the image enters zero-padded to one 32-channel stage (conv1's packed weights are padded alike)
+            cin1 = 32
             x_pad = torch.zeros(N, H, W, cin1, dtype=self.act_dtype, device=dev)
             x_pad[..., :C_] = x_nhwc
             x_nhwc = x_pad
@@ -567,10 +567,10 @@ class GeneratorEngine:
         g_out = g_out.contiguous().float()
         h16 = self.precision in H16_DTYPE
         if h16:
-            # 16-bit storage: the (loss-scaled) output gradient enters zero-padded to one 16-channel chunk
-            go = torch.zeros(N, h, w, 16, dtype=self.act_dtype, device=dev)
+            # 16-bit storage: the (loss-scaled) output gradient enters zero-padded to one 32-channel stage
+            go = torch.zeros(N, h, w, 32, dtype=self.act_dtype, device=dev)
             go[..., :C_] = g_out.permute(0, 2, 3, 1)
-            cgo = 16
+            cgo = 32
         elif C_ == 1:
             go = g_out.view(N, h, w, 1)
             cgo = C_
@@ -605,7 +605,7 @@ class GeneratorEngine:
             # out = out3 + out: both paths; then LeakyReLU' of the upsample output
             up_last = ups[-1]
             g_sum = g_chain + g_cur
-            g_cur = g_sum * torch.where(up_last[..., :F_] > 0, 1.0, G_SLOPE)
+            g_cur = (g_sum * torch.where(up_last[..., :F_] > 0, 1.0, G_SLOPE).to(g_sum.dtype)).contiguous()
 
         # upsampling stages, last to first
         hh, ww = h, w

@@ -104,6 +104,7 @@ class Stepper:
         if distributed and not self.generator.modulewise:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         self.last = {}
+        self._grad_scaler = None      # fp16 activation storage (engine.precision == "fp16"): dynamic loss scaling, created on first use
         # the two discriminators of the D phase run on two streams (133.4 vs 135.3 ms per iteration); SRK_D_STREAMS=0: one stream.
         # Single-process runs only: under data parallelism the D losses exchange batch statistics INSIDE their forward / backward
         # (exact_dp), and collectives issued from side streams gained nothing with RCCL (1 rank: 136.1 vs 136.5 ms) and were
@@ -139,6 +140,29 @@ class Stepper:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
+    def _scaler(self):
+        """Dynamic loss scaling for the generator's backward when its activations / gradients are stored in fp16 (BASELINE configs[4]):
+        the gradient buffers hold S x the true gradients (an L1 loss over 8 x 3 x 512 x 512 outputs starts at 1.6e-7 per element, below
+        fp16's normal range), the fp32 weight gradients come out scaled and fused Adam divides by S; a step whose gradients
+        overflowed is skipped and S halved (torch.amp.GradScaler: device-side, no host sync).  None in every other mode."""
+        if getattr(self.generator, "modulewise", False) or self.generator._engine.precision != "fp16":
+            return None
+        if self._grad_scaler is None:
+            self._grad_scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16)
+        return self._grad_scaler
+
+    def _backward_and_step_G(self, loss):
+        sc = self._scaler()
+        if sc is None:
+            loss.backward()
+            if self.generator.modulewise:
+                self._sync_grads(self.generator)
+            self.optimizer_G.step()
+            return
+        sc.scale(loss).backward()
+        sc.step(self.optimizer_G)
+        sc.update()
+
     def step(self, imgs_lr, imgs_hr):
         if self.workload == "g_only":
             return self.warmup_step(imgs_lr, imgs_hr)
@@ -173,10 +197,7 @@ class Stepper:
         self.optimizer_G.zero_grad(set_to_none=True)
         gen_hr = self.generator(imgs_lr)
         loss_pixel = self.criterion_pixel(gen_hr, imgs_hr)
-        loss_pixel.backward()
-        if self.generator.modulewise:
-            self._sync_grads(self.generator)
-        self.optimizer_G.step()
+        self._backward_and_step_G(loss_pixel)
         self.last = {"g_loss": loss_pixel.detach()}
         return self.last
 
@@ -317,10 +338,7 @@ class Stepper:
             # (not while bench.py brackets every launch with events: the per-kernel times of the probed step must not overlap)
             if self._d_streams is not None and self._d_overlap and update_d and not L.KernelTimer.active:
                 pre_backward = torch.cuda.current_stream().record_event()
-            loss_G.backward()
-            if self.generator.modulewise:
-                self._sync_grads(self.generator)
-            self.optimizer_G.step()
+            self._backward_and_step_G(loss_G)
             # drop the 702 gradient views now, while the GPU is busy with the D phase: at the top of the next iteration this
             # loop would sit on the host's critical path right after the discriminator gate's sync
             self.optimizer_G.zero_grad(set_to_none=True)
