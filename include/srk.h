@@ -96,6 +96,10 @@ typedef struct srk_conv_args {
 #define SRK_CONV_OUT_F32 1
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
+/* n of them launched back to back on `stream`, in array order, from ONE call: the five forward (or five data-gradient) convolutions of
+ * a DenseResidualBlock (models.py:34-41), whose buffers all exist before the first launch.  Stops at the first failing launch and
+ * returns its status. */
+int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
 
 /* Weight-gradient of the same convolution:
  *   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]

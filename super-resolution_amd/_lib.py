@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -91,6 +91,7 @@ def lib():
         L.srk_debug_set_h16_mt.argtypes = [C.c_int]
         L.srk_pack_weights_h16.argtypes = [_fp, C.c_int, C.c_int64, C.c_int, _fp]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
+        L.srk_conv3x3_seq.argtypes = [C.POINTER(ConvArgs), C.c_int, _fp]
         L.srk_debug_set_conv_small.argtypes = [C.c_int]
         L.srk_debug_set_wino42_nmt.argtypes = [C.c_int]
         L.srk_conv3x3_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]
@@ -206,10 +207,9 @@ def _conv_kernel_name(a) -> str:
     return buf.value.decode()
 
 
-def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
-            ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
-            mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0, flags=0):
-    a = ConvArgs()
+def _fill_conv_args(a, x: View, wp, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
+                    ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
+                    mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0, flags=0):
     a.in_slope = in_slope
     a.wp_format = getattr(wp, "fmt", wp_format)
     a.flags = flags
@@ -233,11 +233,16 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, C
     a.slope = slope
     if mask is not None:
         a.mask, a.m_ldc, a.m_coff, a.mask_slope = mask.t.data_ptr(), mask.ldc, mask.coff, mask_slope
+
+
+def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):
+    a = ConvArgs()
+    _fill_conv_args(a, x, wp, bias, y, **kw)
     if KernelTimer.active:
         name = _conv_kernel_name(a)
         if KernelTimer.detail:       # diagnostic split by problem shape and by what the fused epilogue reads
-            name += f" Cin={Cin} Cout={Cout} {OH}x{OW} epi={'b' if bias is not None else ''}{'r' if r1 is not None else ''}{'R' if r2 is not None else ''}{'m' if mask is not None else ''}"
-        e0, e1 = KernelTimer.bracket(name, 2.0 * N * OH * OW * Cout * Cin * 9)
+            name += f" Cin={a.Cin} Cout={a.Cout} {a.OH}x{a.OW} epi={'b' if bias is not None else ''}{'r' if a.r1 else ''}{'R' if a.r2 else ''}{'m' if a.mask else ''}"
+        e0, e1 = KernelTimer.bracket(name, 2.0 * a.N * a.OH * a.OW * a.Cout * a.Cin * 9)
         e0.record()
         check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
         e1.record()
@@ -245,7 +250,23 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, *, N, H, W, OH, OW, Cin, C
     check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
 
 
+def conv3x3_seq(calls):
+    """``calls``: list of (x, wp, bias, y, kwargs) as for conv3x3 -- launched back to back on the current stream by ONE C call
+    (srk_conv3x3_seq: a dense block's five forward or five data-gradient convolutions).  While bench.py brackets launches with
+    events they go one by one, so that every launch keeps its own time."""
+    if KernelTimer.active:
+        for x, wp, bias, y, kw in calls:
+            conv3x3(x, wp, bias, y, **kw)
+        return
+    n = len(calls)
+    arr = (ConvArgs * n)()
+    for a, (x, wp, bias, y, kw) in zip(arr, calls):
+        _fill_conv_args(a, x, wp, bias, y, **kw)
+    check(lib().srk_conv3x3_seq(arr, n, stream_ptr()), "srk_conv3x3_seq")
+
+
 _ws_cache = {}
+_wgrad_ws_bytes = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -301,9 +322,14 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
         a.scale, a.accumulate = p.get("scale", 1.0), int(p.get("accumulate", False))
         a.precision = precision
         flops += 2.0 * N * OH * OW * a.Cout * a.Cin * 9
-    nbytes = C.c_size_t(0)
-    check(lib().srk_conv3x3_wgrad_batched_workspace(arr, n, C.byref(nbytes)), "srk_conv3x3_wgrad_batched_workspace")
-    ws = _workspace(nbytes.value, problems[0]["x"].t.device)
+    # (the workspace size depends on the geometry only: one query per shape, not one more C call per launch)
+    key = (N, H, W, OH, OW, stride, dy_mode, precision, tuple((a.Cin, a.Cout) for a in arr))
+    need = _wgrad_ws_bytes.get(key)
+    if need is None:
+        nbytes = C.c_size_t(0)
+        check(lib().srk_conv3x3_wgrad_batched_workspace(arr, n, C.byref(nbytes)), "srk_conv3x3_wgrad_batched_workspace")
+        need = _wgrad_ws_bytes[key] = nbytes.value
+    ws = _workspace(need, problems[0]["x"].t.device)
     arr[0].workspace, arr[0].workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
         e0, e1 = KernelTimer.bracket(_wgrad_kernel_name(arr, n) + "+reduce", flops)

@@ -1167,6 +1167,15 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
   }
 }
 
+extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
+  if (!args || n <= 0) return SRK_ERR_BAD_ARG;
+  for (int i = 0; i < n; ++i) {
+    const int rc = srk_conv3x3(args + i, stream);
+    if (rc) return rc;
+  }
+  return SRK_OK;
+}
+
 // Name (as rocprofv3 prints it) of the kernel srk_conv3x3 dispatches to for these arguments; launches nothing.  The
 // measurement harness labels its per-launch event times with it, so the dispatch rules live in this file only.
 extern "C" int srk_conv3x3_kernel_name(const srk_conv_args* pa, char* buf, size_t len) {

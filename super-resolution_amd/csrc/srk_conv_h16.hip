@@ -34,8 +34,10 @@ namespace {
 #ifdef SRK_STAMP       // diagnostic build only (make stamp; tools/stamp_h16.py): phase stamps of wave 0 of every workgroup
 __device__ unsigned long long* g_h16_stamps = nullptr;
 #define H16_STAMP(k) do { if (threadIdx.x == 0 && g_h16_stamps) { g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define H16_STAMP_L(k) do { if (threadIdx.x == 256 && g_h16_stamps) { g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define H16_STAMP(k) do { } while (0)
+#define H16_STAMP_L(k) do { } while (0)
 #endif
 
 template <typename T> struct H16;
@@ -68,10 +70,8 @@ template <int MT> struct HGeo {
   static constexpr int TH = 4 * MT, IH = TH + 2, NHP = IH * HW_IW;        // halo pixels (612 / 340)
   static constexpr int HPIECES = (4 * NHP + 63) / 64;                    // 1-KB DMA pieces (16 pixels each) of the halo (39 / 22)
   static constexpr int WPIECES = 36;                                      // [k-step][tap][k-half] x 64 couts x 16 B
-  static constexpr int STAGE4 = (HPIECES + WPIECES + 1) * 64;             // 16-byte slots per stage (+ one dummy piece, below)
+  static constexpr int STAGE4 = (HPIECES + WPIECES) * 64;                 // 16-byte slots per stage
   static constexpr int WBASE = HPIECES * 64;
-  static constexpr int DUMMY = (HPIECES + WPIECES) * 64;                  // where the zeros of a piece that does not exist land
-  static constexpr int NJH = (HPIECES + 3) / 4, NJW = WPIECES / 4;        // pieces per wave (10 / 6 halo, 9 weight)
 };
 
 // ------------------------------------------------------------------------------------------------------------------ epilogue
@@ -217,8 +217,11 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 }
 
 // ------------------------------------------------------------------------------------------------------------------ kernel
+constexpr int H16_NLOAD = 2;                            // loader waves
+constexpr int H16_THREADS = 64 * (4 + H16_NLOAD);
+
 template <typename T, int MODE, int MT, bool OUTF32>
-__global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a) {
+__global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_conv_args a) {
   typedef typename H16<T>::v8 v8;
   typedef HGeo<MT> G;
   constexpr int SMEM4 = 2 * G::STAGE4 > 2048 ? 2 * G::STAGE4 : 2048;       // >= 4 x 8 KB of epilogue scratch
@@ -241,61 +244,76 @@ __global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a)
   const int nq = a.Cin >> 5;                          // stages of 32 input channels
   H16_STAMP(0);
 
-  // ---- DMA plan
-  const T* xbase = reinterpret_cast<const T*>(a.x);
-  const int Cps_in = a.Cin >> 2;
-  long img_elems = (long)a.H * a.W * a.x_ldc;
-  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
-  const T* ximg = xbase + (long)n * img_elems;
-  const unsigned xbytes = (unsigned)(img_elems * 2);
-  const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
-  unsigned xvo[G::NJH];
-  {
-    const int ih0 = oh0 - 1, iw0 = ow0 - 1;
+  if (wv >= 4) {
+    // ------------------------------------------------------------------------------------------------------ loader waves
+    // The MFMA waves issue no vector-memory instruction in the main loop: a buffer_load ... lds costs the issuing wave 100-185
+    // cycles beside MFMAs and LDS reads (stamps: 19 pieces per wave and stage inflated a 4608-cycle stage to 6200-7300), and with
+    // one wave per SIMD nothing hides that.  Two waves of their own (sharing SIMDs 0 and 2 with MFMA waves, <= 256 registers each)
+    // issue the 75 pieces of a stage -- piece lw + 2 j: halo pieces first (HBM), then the weight pieces (L2) -- right behind the
+    // barrier that frees its buffer, wait for them and meet the MFMA waves at the next stage barrier.
+    const int lw = wv - 4;
+    const T* xbase = reinterpret_cast<const T*>(a.x);
+    const int Cps_in = a.Cin >> 2;
+    long img_elems = (long)a.H * a.W * a.x_ldc;
+    if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+    const T* ximg = xbase + (long)n * img_elems;
+    const unsigned xbytes = (unsigned)(img_elems * 2);
+    const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+    constexpr int NXJ = (G::HPIECES + H16_NLOAD - 1) / H16_NLOAD, NWJ = G::WPIECES / H16_NLOAD;
+    unsigned xvo[NXJ];
+    {
+      const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-    for (int j = 0; j < G::NJH; ++j) {
-      const int hp = (wv + 4 * j) * 16 + (lane >> 2);                   // halo pixel of this lane in piece wv + 4 j
-      const int g = (lane & 3) ^ ((hp >> 2) & 3);                       // the 8-channel group its slot holds
-      const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
-      const int ih = ih0 + hy, iw = iw0 + hx;
-      unsigned v = H_OOB;
-      if (hp < G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
-        long off;
-        if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * g;
-        else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * g;
-        v = (unsigned)(off * 2);
+      for (int j = 0; j < NXJ; ++j) {
+        const int hp = (lw + H16_NLOAD * j) * 16 + (lane >> 2);            // halo pixel of this lane in piece lw + 2 j
+        const int g = (lane & 3) ^ ((hp >> 2) & 3);                        // the 8-channel group its slot holds
+        const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
+        const int ih = ih0 + hy, iw = iw0 + hx;
+        unsigned v = H_OOB;
+        if (hp < G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
+          long off;
+          if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * g;
+          else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * g;
+          v = (unsigned)(off * 2);
+        }
+        xvo[j] = v;
       }
-      xvo[j] = v;
     }
-  }
-  const unsigned wvo = (unsigned)((n0 + lane) * 16);
-  // One DMA piece (1 KB: 16 bytes per lane) of stage q into buffer b.  Piece j < NJH: halo piece wv + 4 j (halo first: it comes from
-  // HBM, the weights from L2); else weight piece (k-step, tap, k-half) = wv + 4 (j - NJH), which is contiguous in the packed
-  // weights.  A piece that does not exist (past the last stage; the waves' uneven halo shares) goes through a descriptor of ZERO
-  // records: nothing is read, and the zeros an out-of-range DMA still writes land in the stage's DUMMY piece, which nobody reads --
-  // scalar selects, no branch in the main loop.
-  constexpr int NPIECE = G::NJH + G::NJW;
-  auto piece = [&](int q, auto bc, auto jc) {
-    constexpr int b = decltype(bc)::value, j = decltype(jc)::value;
-    float4* dst = smem + b * G::STAGE4;
-    if constexpr (j < G::NJH) {
+    const unsigned wvo = (unsigned)((n0 + lane) * 16);
+    auto stage = [&](int q, int b) {
       unsigned xso = (unsigned)(32 * q * 2);
       if (MODE == SRK_IN_UNSHUFFLE) {
         const int c32 = 32 * q;
         const int ij = c32 / Cps_in, c = c32 - ij * Cps_in;
         xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
       }
-      const int i = wv + 4 * j;
-      const bool live = q < nq && i < G::HPIECES;            // (with zero records every lane is out of range whatever the offsets)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, live ? xbytes : 0u, 0x00020000);
-      h16_dma(rs, dst + (i < G::HPIECES ? i * 64 : G::DUMMY), xvo[j], xso);
-    } else {
-      const int w = wv + 4 * (j - G::NJH);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, q < nq ? wbytes : 0u, 0x00020000);
-      h16_dma(rs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
+      float4* dst = smem + b * G::STAGE4;
+#pragma unroll
+      for (int j = 0; j < NXJ; ++j) {
+        const int i = lw + H16_NLOAD * j;
+        if (i < G::HPIECES) h16_dma(xrs, dst + i * 64, xvo[j], xso);
+      }
+#pragma unroll
+      for (int j = 0; j < NWJ; ++j) {
+        const int w = lw + H16_NLOAD * j;                                  // (k-step, tap, k-half): contiguous in the packed weights
+        h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
+      }
+    };
+    stage(0, 0);
+    H16_STAMP_L(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int q = 0; q < nq; ++q) {
+      if (q + 1 < nq) stage(q + 1, (q + 1) & 1);        // its buffer held stage q - 1: every read of it returned before the barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-  };
+    return;
+  }
 
+  // ---------------------------------------------------------------------------------------------------------- MFMA waves
   f32x16 acc[MT][2];
   // ---- fragment addresses (bytes from smem).  A: halo pixel p = (MT wv + ri) * 34 + l32 + s of the (ri, s) this step reads, k-step 0;
   // k-step 1 = the same XOR 32; the other buffer = + STAGE bytes.  B: [k-step][tap][k-half][64 couts] 16-byte slots behind the halo.
@@ -311,12 +329,15 @@ __global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a)
 
   // ---- main loop.  A stage is STEPS = 2 x 3 (MT + 2) steps L: k-step kk, column shift s, halo row ri; one A fragment feeds the kernel
   // rows r with output row m = ri - r in range, both channel halves: 2 / 4 / 6 MFMAs.  Fragments are read AHEAD, by hand:
-  //   A(L + 2) at step L into a ring of four register sets;  the six B fragments of the next (k-step, shift) group during steps
-  //   ri = 1..3 of the current one into the other of two sets;  the DMA pieces of the next stage one per step, halo first.
-  // The last two steps of a stage are issued BEHIND the stage barrier and the first reads of the next stage, so that the matrix
-  // pipe has work while those reads are in flight (one workgroup per CU: nothing else would cover them).  Straight-line code
-  // (sched_barrier between the slots); two stages per loop iteration make the buffer a compile-time constant.
-  v8 Af[4], Bf[2][3][2];
+  //   A(L + 4) at step L into a ring of eight register sets (four steps hold at least 12 MFMAs = 384 cycles);  the six B fragments of
+  //   the next (k-step, shift) group during steps ri = 1..3 of the current one into the other of two sets.
+  // The last FOUR steps of a stage (12 - 18 MFMAs) are issued BEHIND the stage barrier and the first ten reads of the next stage, so
+  // that the matrix pipe has work while those reads are in flight (one MFMA wave per SIMD: nothing else would cover them).
+  // Straight-line code (sched_barrier between the slots); two stages per loop iteration make the buffer and the ring phase
+  // compile-time constants.
+  constexpr int DEFER = 4, AHEAD = 4;
+  constexpr int RINGP = STEPS & 7;                     // ring phase of the odd stage of a pair (36 steps: 4; 24 steps: 0)
+  v8 Af[8], Bf[2][3][2];
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   const char* sm = reinterpret_cast<const char*>(smem);
   auto rdA = [&](int P, int L) {         // (P, L are constants after unrolling)
@@ -327,61 +348,54 @@ __global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a)
     const int kk = S / 3, s = S % 3;
     return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + P * (G::STAGE4 * 16) + baddr + ((kk * 18 + (3 * r + s) * 2) * 64 + 32 * t) * 16));
   };
-  auto mfma_step = [&](auto lc) {
-    constexpr int L = decltype(lc)::value;
+  auto mfma_step = [&](auto pc, auto lc) {
+    constexpr int P = decltype(pc)::value, L = decltype(lc)::value;
     constexpr int S = L / SPS, ri = L % SPS;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int m = ri - r;
       if (m >= 0 && m < MT) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[L & 3], Bf[S & 1][r][t], acc[m][t]);
+        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[(RINGP * P + L) & 7], Bf[S & 1][r][t], acc[m][t]);
       }
     }
   };
-  auto head = [&](auto pc) {          // first fragments of the stage in buffer P: the six B fragments of group 0, A(0), A(1)
+  auto head = [&](auto pc) {          // first fragments of the stage in buffer P: the six B fragments of group 0, A(0) .. A(AHEAD - 1)
     constexpr int P = decltype(pc)::value;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int t = 0; t < 2; ++t) Bf[0][r][t] = rdB(P, 0, r, t);
-    Af[0] = rdA(P, 0);
-    Af[1] = rdA(P, 1);
+#pragma unroll
+    for (int L = 0; L < AHEAD; ++L) Af[(RINGP * P + L) & 7] = rdA(P, L);
   };
-  auto stage_fn = [&](int q, auto pc) {
+  auto stage_fn = [&](auto pc) {
     constexpr int P = decltype(pc)::value;
     using Pc = std::integral_constant<int, P>; using Pn = std::integral_constant<int, P ^ 1>;
     auto step = [&](auto lc) {
       constexpr int L = decltype(lc)::value;
       constexpr int S = L / SPS, ri = L % SPS;
-      Af[(L + 2) & 3] = rdA(P, L + 2);
+      if constexpr (L + AHEAD < STEPS) Af[(RINGP * P + L + AHEAD) & 7] = rdA(P, L + AHEAD);
       if constexpr (ri >= 1 && ri <= 3 && S < 5) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) Bf[(S + 1) & 1][ri - 1][t] = rdB(P, S + 1, ri - 1, t);
       }
-      if constexpr (L + 2 < NPIECE) piece(q + 1, Pn{}, std::integral_constant<int, (L + 2 < NPIECE ? L + 2 : 0)>{});
       __builtin_amdgcn_sched_barrier(0);
-      mfma_step(lc);
+      mfma_step(Pc{}, lc);
       __builtin_amdgcn_sched_barrier(0);
     };
-    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - 2>{});
-    // every piece of stage q + 1 has landed (mine: vmcnt; the others': behind the barrier) and every read of this stage's buffer has
-    // returned (the DMA of stage q + 2 may overwrite it)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - DEFER>{});
+    // every read of this stage's buffer has returned (behind the barrier the loaders overwrite it with stage q + 2); behind the
+    // barrier the loaders' pieces of stage q + 1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    head(Pn{});
-    piece(q + 2, Pc{}, I0{});
-    piece(q + 2, Pc{}, I1{});
+    head(Pn{});          // (behind the LAST stage: reads of a buffer nobody fills any more, into registers nobody uses -- no branch)
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(std::integral_constant<int, STEPS - 2>{});
-    mfma_step(std::integral_constant<int, STEPS - 1>{});
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (mfma_step(Pc{}, std::integral_constant<int, STEPS - DEFER + Ls>{}), ...); }(std::make_integer_sequence<int, DEFER>{});
     __builtin_amdgcn_sched_barrier(0);
   };
-  static_assert(NPIECE <= STEPS - 2 && (STEPS & 3) == 0, "one DMA piece per step; the A ring must close over a stage");
+  static_assert((STEPS & 3) == 0 && ((2 * STEPS) & 7) == 0, "the A ring must close over a pair of stages");
 
-  [&]<int... Js>(std::integer_sequence<int, Js...>) { (piece(0, I0{}, std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, NPIECE>{});
-  H16_STAMP(1);
-  __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first stage is in flight
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -389,23 +403,21 @@ __global__ __launch_bounds__(256) void conv3x3_h16_kernel(const srk_conv_args a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();          // stage 0 is in LDS
   H16_STAMP(2);
   head(I0{});
-  piece(1, I1{}, I0{});
-  piece(1, I1{}, I1{});
   {
     int q = 0;
     for (; q + 1 < nq; q += 2) {
-      stage_fn(q, I0{});
-      stage_fn(q + 1, I1{});
+      stage_fn(I0{});
+      stage_fn(I1{});
     }
-    if (q < nq) stage_fn(q, I0{});
+    if (q < nq) stage_fn(I0{});
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (empty) pieces and the reads of a chunk that does not exist
+  // (no barrier in front of the epilogue: behind the last stage barrier no wave reads staged data any more, the loaders have
+  // nothing in flight, and every wave's transposition scratch is its own)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   H16_STAMP(3);
-  __builtin_amdgcn_s_barrier();          // the epilogue reuses the staging buffers
   float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
   const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
   if constexpr (OUTF32) {
@@ -472,8 +484,8 @@ int g_h16_mt = -1;
 
 #define H16_LAUNCH(T, MODE, MT)                                                                                        \
   do {                                                                                                                 \
-    if (a.flags & SRK_CONV_OUT_F32) hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, true>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, false>), grid, dim3(256), 0, st, a);                      \
+    if (a.flags & SRK_CONV_OUT_F32) hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, true>), grid, dim3(H16_THREADS), 0, st, a); \
+    else hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, false>), grid, dim3(H16_THREADS), 0, st, a);                      \
   } while (0)
 
 int launch_h16_any(const srk_conv_args& a, int mt, hipStream_t st) {

@@ -360,28 +360,32 @@ class GeneratorEngine:
         for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53)."""
         N, H, W = geo
         F_ = pk.F
+        calls = []          # the block's five convolutions go to the library in ONE call (srk_conv3x3_seq)
         for k in range(1, 5):
-            L.conv3x3(View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_),
-                      N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)
+            calls.append((View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_),
+                          dict(N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)))
         b5 = d.b5[0].bias.data
         if outer_x is None:
-            L.conv3x3(View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
-                      alpha=INNER_RES_SCALE, r1=View(D, 0, F_), beta1=1.0)
+            calls.append((View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                          alpha=INNER_RES_SCALE, r1=View(D, 0, F_), beta1=1.0)))
         else:
-            L.conv3x3(View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
-                      alpha=INNER_RES_SCALE * rs, r1=View(D, 0, F_), beta1=rs, r2=outer_x, beta2=1.0)
+            calls.append((View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                          alpha=INNER_RES_SCALE * rs, r1=View(D, 0, F_), beta1=rs, r2=outer_x, beta2=1.0)))
+        L.conv3x3_seq(calls)
 
     def _drb_backward(self, d, pk: DrbPack, D, E, gx_out: View, geo, beta_self: float, outer_g: Optional[View], grads: Dict):
         """Backward of one DenseResidualBlock.  E slice 0 holds the (unscaled) gradient of the block output; slices
         1..4 receive dy4..dy1.  Writes the block-input gradient to ``gx_out``."""
         N, H, W = geo
         F_ = pk.F
+        calls = []          # the five data-gradient convolutions in ONE library call
         for m in range(4, 0, -1):
             K = (5 - m) * F_
-            L.conv3x3(View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_,
-                      mask=View(D, m * F_, F_), mask_slope=G_SLOPE)
-        L.conv3x3(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
-                  r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)
+            calls.append((View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), dict(N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_,
+                          mask=View(D, m * F_, F_), mask_slope=G_SLOPE)))
+        calls.append((View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
+                      r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)))
+        L.conv3x3_seq(calls)
         # weight gradients: conv k reads D[0:kF), its dy is E slice (5-k) (k=5: slice 0 scaled by s5).
         # One batched launch for the five convs (15 chunks of 64x64x9).
         probs = []
