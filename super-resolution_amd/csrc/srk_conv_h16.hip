@@ -100,6 +100,8 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bq[e] = b0[e]; bq[4 + e] = b1[e]; }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bq[e] *= a.alpha;          // (acc + bias) * alpha = fma(acc, alpha, alpha * bias)
   }
   const float* r1p = srk_sgpr_opaque(a.r1); const float* r2p = srk_sgpr_opaque(a.r2); const float* mkp = srk_sgpr_opaque(a.mask);
   const bool has_r1 = r1p != nullptr, has_r2 = r2p != nullptr;
@@ -179,22 +181,33 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
       for (int j = 0; j < 4; ++j) {
         const int pl = 8 * j + plb;
         const f32x4 v0 = ls4[pl * 16 + 2 * c8], v1 = ls4[pl * 16 + 2 * c8 + 1];
+        // One wave per SIMD: every VALU instruction of the epilogue costs its full 4 cycles and nothing hides it (stamps: 3.2 us of
+        // a 20-50 us launch).  Hence: bias folded into one fused multiply-add (bq holds alpha * bias), wave-uniform branches around
+        // what a launch does not use (no LeakyReLU on the data-gradient convs, no residual arithmetic for a mask slot and vice
+        // versa), LeakyReLU as max(o, slope * o) (0 <= slope <= 1, host-checked) instead of compare + select, whose SGPR mask
+        // costs wait states.
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = (v0[e] + bq[e]) * alpha; o[4 + e] = (v1[e] + bq[4 + e]) * alpha; }
+        for (int e = 0; e < 4; ++e) { o[e] = __builtin_fmaf(v0[e], alpha, bq[e]); o[4 + e] = __builtin_fmaf(v1[e], alpha, bq[4 + e]); }
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) {
-          const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
+          if (sres[sidx]) {
+            const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += scoef[sidx] * (sres[sidx] ? rv[e] : 0.f);
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(scoef[sidx], rv[e], o[e]);
+          }
+        }
+        if (slope != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaxf(o[e], o[e] * slope);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * slope;
-#pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) {
-          const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
+          if (!sres[sidx]) {
+            const h16_f32x8 rv = __builtin_convertvector(sv[sidx][mm][j], h16_f32x8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] *= (rv[e] > 0.f ? 1.f : sms[sidx]);
+            for (int e = 0; e < 8; ++e) o[e] = rv[e] > 0.f ? o[e] : o[e] * sms[sidx];
+          }
         }
         const bool ok = (valid >> (4 * mm + j)) & 1;
         if constexpr (OUTF32) {
@@ -244,6 +257,61 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
   const int nq = a.Cin >> 5;                          // stages of 32 input channels
   H16_STAMP(0);
 
+  // ---- DMA addressing shared by the prologue (all six waves) and the loader waves
+  const T* xbase = reinterpret_cast<const T*>(a.x);
+  const int Cps_in = a.Cin >> 2;
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const T* ximg = xbase + (long)n * img_elems;
+  const unsigned xbytes = (unsigned)(img_elems * 2);
+  const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
+  const unsigned wvo = (unsigned)((n0 + lane) * 16);
+  auto halo_vo = [&](int i) -> unsigned {               // per-lane byte offset of halo piece i (16 pixels x four 8-channel groups)
+    const int hp = i * 16 + (lane >> 2);
+    const int g = (lane & 3) ^ ((hp >> 2) & 3);           // the 8-channel group this lane's slot holds
+    const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
+    const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+    // (32-bit arithmetic: the host checks that one image of x stays below 2^31 bytes)
+    unsigned off;
+    if (MODE == SRK_IN_UNSHUFFLE) off = (unsigned)((2 * ih) * (2 * a.W) + 2 * iw) * (unsigned)a.x_ldc + (unsigned)(a.x_coff + 8 * g);
+    else off = (unsigned)(ih * a.W + iw) * (unsigned)a.x_ldc + (unsigned)(a.x_coff + 8 * g);
+    const bool ok = hp < G::NHP && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    return ok ? off * 2u : H_OOB;
+  };
+  // Stages run over the input channels LAST BLOCK FIRST: in a dense block (forward and data gradient alike) the highest channels
+  // of the prefix are the slice the previous launch has just written -- by the same tiles on the same XCDs (the tile -> XCD map is
+  // the same for every launch of a grid) --, so the first stage, which nothing can hide, comes out of L2 instead of HBM, and the
+  // older slices stream in behind the main loop.  (The K order only changes the order of the fp32 sums.)
+  auto halo_so = [&](int qs) -> unsigned {              // scalar byte offset of stage qs's 32 input channels
+    const int q = nq - 1 - qs;
+    if (MODE == SRK_IN_UNSHUFFLE) {
+      const int c32 = 32 * q;
+      const int ij = c32 / Cps_in, c = c32 - ij * Cps_in;
+      return (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
+    }
+    return (unsigned)(32 * q * 2);
+  };
+  // ---- prologue: stage 0 is issued by ALL six waves, piece wv + 6 j each (one wave streams ~25 GB/s of DMA at best, and until the
+  // first stage has landed the MFMA waves have nothing else to do)
+  {
+    // (the weight pieces first: their addresses need no arithmetic, so the memory system is at work while the halo offsets are formed)
+    constexpr int NW0 = G::WPIECES / 6, NH0 = (G::HPIECES + 5) / 6;
+#pragma unroll
+    for (int j = 0; j < NW0; ++j) {
+      const int w = wv + 6 * j;
+      h16_dma(wrs, smem + G::WBASE + w * 64, wvo, (unsigned)(((nq - 1) * 36 + w) * CoutP * 16));
+    }
+    const unsigned xso0 = halo_so(0);
+#pragma unroll
+    for (int j = 0; j < NH0; ++j) {
+      const int i = wv + 6 * j;
+      if (i < G::HPIECES) h16_dma(xrs, smem + i * 64, halo_vo(i), xso0);
+    }
+    H16_STAMP(6);
+  }
+
   if (wv >= 4) {
     // ------------------------------------------------------------------------------------------------------ loader waves
     // The MFMA waves issue no vector-memory instruction in the main loop: a buffer_load ... lds costs the issuing wave 100-185
@@ -252,43 +320,12 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
     // issue the 75 pieces of a stage -- piece lw + 2 j: halo pieces first (HBM), then the weight pieces (L2) -- right behind the
     // barrier that frees its buffer, wait for them and meet the MFMA waves at the next stage barrier.
     const int lw = wv - 4;
-    const T* xbase = reinterpret_cast<const T*>(a.x);
-    const int Cps_in = a.Cin >> 2;
-    long img_elems = (long)a.H * a.W * a.x_ldc;
-    if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
-    const T* ximg = xbase + (long)n * img_elems;
-    const unsigned xbytes = (unsigned)(img_elems * 2);
-    const unsigned wbytes = (unsigned)((long)nq * 36 * CoutP * 16);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, wbytes, 0x00020000);
     constexpr int NXJ = (G::HPIECES + H16_NLOAD - 1) / H16_NLOAD, NWJ = G::WPIECES / H16_NLOAD;
     unsigned xvo[NXJ];
-    {
-      const int ih0 = oh0 - 1, iw0 = ow0 - 1;
 #pragma unroll
-      for (int j = 0; j < NXJ; ++j) {
-        const int hp = (lw + H16_NLOAD * j) * 16 + (lane >> 2);            // halo pixel of this lane in piece lw + 2 j
-        const int g = (lane & 3) ^ ((hp >> 2) & 3);                        // the 8-channel group its slot holds
-        const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
-        const int ih = ih0 + hy, iw = iw0 + hx;
-        unsigned v = H_OOB;
-        if (hp < G::NHP && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
-          long off;
-          if (MODE == SRK_IN_UNSHUFFLE) off = ((long)(2 * ih) * (2 * a.W) + 2 * iw) * a.x_ldc + a.x_coff + 8 * g;
-          else off = ((long)ih * a.W + iw) * a.x_ldc + a.x_coff + 8 * g;
-          v = (unsigned)(off * 2);
-        }
-        xvo[j] = v;
-      }
-    }
-    const unsigned wvo = (unsigned)((n0 + lane) * 16);
-    auto stage = [&](int q, int b) {
-      unsigned xso = (unsigned)(32 * q * 2);
-      if (MODE == SRK_IN_UNSHUFFLE) {
-        const int c32 = 32 * q;
-        const int ij = c32 / Cps_in, c = c32 - ij * Cps_in;
-        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
-      }
+    for (int j = 0; j < NXJ; ++j) xvo[j] = halo_vo(lw + H16_NLOAD * j);
+    auto stage = [&](int qs, int b) {
+      const unsigned xso = halo_so(qs);
       float4* dst = smem + b * G::STAGE4;
 #pragma unroll
       for (int j = 0; j < NXJ; ++j) {
@@ -298,10 +335,9 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
 #pragma unroll
       for (int j = 0; j < NWJ; ++j) {
         const int w = lw + H16_NLOAD * j;                                  // (k-step, tap, k-half): contiguous in the packed weights
-        h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
+        h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)(((nq - 1 - qs) * 36 + w) * CoutP * 16));
       }
     };
-    stage(0, 0);
     H16_STAMP_L(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -403,6 +439,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my share of stage 0
   __builtin_amdgcn_s_barrier();          // stage 0 is in LDS
   H16_STAMP(2);
   head(I0{});
@@ -526,6 +563,7 @@ int srk_conv_h16_mt(const srk_conv_args& a) {
 int srk_conv_h16_check(const srk_conv_args& a) {
   if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.Cin <= 0 || a.Cout <= 0) return SRK_ERR_BAD_ARG;
   if (a.stride != 1 || (a.in_mode != SRK_IN_PLAIN && a.in_mode != SRK_IN_UNSHUFFLE) || (a.Cin % 32) || a.in_slope != 1.f) return SRK_ERR_UNSUPPORTED;
+  if (!(a.slope >= 0.f && a.slope <= 1.f)) return SRK_ERR_UNSUPPORTED;       // LeakyReLU as max(t, slope * t)
   if (a.OH != a.H || a.OW != a.W) return SRK_ERR_BAD_ARG;
   if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 32))) return SRK_ERR_UNSUPPORTED;
   if ((a.x_ldc % 8) || (a.x_coff % 8) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;

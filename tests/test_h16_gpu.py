@@ -263,7 +263,7 @@ def _mrel(a, b):
 # relative to the tensor's max-abs against the CPU fp32 oracle.  A 16-bit rounding per stored activation (fp16: 2^-11, bf16: 2^-8
 # relative) accumulates along 30 / 351 convolutions; measured values are in DESIGN.md section 4d.
 SMALL_TOL = {"fp16": (2e-3, 1e-2), "bf16s": (1.5e-2, 8e-2)}
-FULL_TOL = {"fp16": (4e-3, 2e-2), "bf16s": (3e-2, 1.5e-1)}
+FULL_TOL = {"fp16": (4e-3, 5e-3), "bf16s": (3e-2, 3e-2)}       # measured: fp16 1.8e-3 / 1.6e-3, bf16 1.6e-2 / 1.0e-2
 
 
 @pytest.mark.parametrize("mode", ["fp16", "bf16s"])

@@ -52,5 +52,6 @@ for ci in (64, 192, 320):
     cyc = raw[:, 8 + 3] - raw[:, 8 + 2]; us = (raw[:, 3] - raw[:, 2]) * 0.01
     print("   main loop: %.0f shader cycles per stage (ideal %d), shader clock %.3f GHz, %.2f us per stage"
           % ((cyc / nq).median(), 18 * mt * 2 * 32, (cyc / us).median() * 1e-3, (us / nq).median()))
+    print("   wave 0: its share of stage 0 issued at median %.2f us" % (s[:, 6] - t0).median())
     d = s[:, 1:6] - s[:, 0:5]
     print("   per-workgroup phase medians: setup+issue %.2f | wait stage 0 %.2f | main loop %.2f | epilogue %.2f | drain %.2f us" % tuple(d.median(0).values.tolist()))
