@@ -87,10 +87,12 @@ class GeneratorEngine:
         self.use_graphs = os.environ.get("SRK_GRAPHS", "0") == "1"     # hipGraph replay of forward / backward (_GraphSet)
         self._graphs = {}
         self._side = None            # second HIP stream: weight-gradient kernels overlap the data-gradient chain
-        # weight gradients on the side stream: -0.95 ms per GAN iteration (133.2 -> 132.3, three same-box pairs).  Default: on in
-        # single-process runs, off under data parallelism (the bucket all-reduces would move to the side stream with them: never
-        # measured on more than one GPU); SRK_OVERLAP_WGRAD=0 | 1 forces either.
+        self._issue = None           # third stream, carries nothing but the issue points of the bucket all-reduces (_reduce_bucket)
+        # weight gradients on the side stream: -0.95 ms per GAN iteration (133.2 -> 132.3, three same-box pairs).  Default: on, also
+        # under data parallelism (round 3; SRK_DP_SCHEDULE=serial keeps a distributed run on one stream); SRK_OVERLAP_WGRAD=0 | 1
+        # forces either.
         self._overlap_env = os.environ.get("SRK_OVERLAP_WGRAD")
+        self._dp_serial = os.environ.get("SRK_DP_SCHEDULE", "overlap") == "serial"
 
     @property
     def act_dtype(self):
@@ -108,14 +110,14 @@ class GeneratorEngine:
         if self._overlap_env is not None:
             return self._overlap_env != "0"
         # (not while bench.py brackets every launch with events -- the per-kernel times must not overlap -- nor with hipGraph replay)
-        return not self._sync and not self.use_graphs and not L.KernelTimer.active
+        return not (self._sync and self._dp_serial) and not self.use_graphs and not L.KernelTimer.active
 
     def __getstate__(self):
         """Pickling / torch.save(module) / multiprocessing spawn: everything but the module reference and the flags is a cache
         (packed weights, pack tables, graphs, streams) that is rebuilt on the first forward."""
-        keep = ("gen", "_sync", "_grad_scale", "precision", "use_graphs", "_overlap_env")
+        keep = ("gen", "_sync", "_grad_scale", "precision", "use_graphs", "_overlap_env", "_dp_serial")
         st = {k: self.__dict__[k] for k in keep}
-        st.update(_sig=None, _graphs={}, _side=None)
+        st.update(_sig=None, _graphs={}, _side=None, _issue=None)
         return st
 
     # ------------------------------------------------------------------ data-parallel gradient exchange
@@ -150,27 +152,33 @@ class GeneratorEngine:
         return grads
 
     def _reduce_bucket(self, key):
+        """Start the all-reduce of one gradient bucket.  Its weight gradients were launched on the main stream and (with the
+        weight-gradient side stream on) on the side stream: the collective is issued from a third, otherwise empty "issue" stream that
+        waits for THIS point of both, so neither the data-gradient chain nor the weight-gradient stream ever waits for a collective.
+        torch.distributed enqueues every collective of a process group on the group's own stream in HOST call order -- which is the
+        same on every rank (same code, same shapes) -- and makes it wait for the stream it was issued from: the order of collectives
+        on the communicator does not depend on the issuing streams, and a collective only ever waits for work that was queued before
+        it, so the schedule cannot introduce a cycle."""
         if not self._sync:
             return
         import torch.distributed as dist
         a, b = self._bucket[key]
         if self._side is not None and self.overlap_wgrad:
-            self._side.wait_stream(torch.cuda.current_stream())      # bucket = side-stream wgrads + main-stream wgrads
-            with torch.cuda.stream(self._side):
+            if self._issue is None:
+                self._issue = torch.cuda.Stream()
+            self._issue.wait_stream(torch.cuda.current_stream())
+            self._issue.wait_stream(self._side)
+            self._flat_grad.record_stream(self._issue)
+            with torch.cuda.stream(self._issue):
                 self._works.append(dist.all_reduce(self._flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
             return
         self._works.append(dist.all_reduce(self._flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def _finish_reduce(self):
-        if self._works and self._side is not None and self.overlap_wgrad:
-            with torch.cuda.stream(self._side):
-                for w in self._works:
-                    w.wait()
-        else:
-            for w in self._works:
-                w.wait()
-        self._works = []
         self._join_side()
+        for w in self._works:          # (the current = main stream waits for every bucket)
+            w.wait()
+        self._works = []
 
     # ------------------------------------------------------------------ parameter bookkeeping
     def _conv_modules(self):

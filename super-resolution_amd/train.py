@@ -25,6 +25,23 @@ from . import losses, models
 EPS = 1e-7   # esrgan.py:319
 
 
+_STAT_GROUP = None
+
+
+def _stat_group():
+    """A process group of its own (all ranks) for the small exchanges: batch statistics of the losses, discriminator gradients, the
+    d_threshold gate.  torch.distributed runs the collectives of ONE group in host call order on that group's stream: on the default
+    group a statistic exchange of the D phase, which runs beside the generator's backward on the discriminator streams, would queue
+    behind every gradient bucket of that backward -- i.e. the D phase would wait for the end of the backward it is meant to overlap.
+    Same host order of the calls on every rank for this group too, so nothing new can deadlock."""
+    global _STAT_GROUP
+    import torch.distributed as dist
+    world = dist.distributed_c10d._get_default_group()
+    if _STAT_GROUP is None or _STAT_GROUP[0] is not world:        # (a new default group after destroy / init: a new statistics group)
+        _STAT_GROUP = (world, dist.new_group())
+    return _STAT_GROUP[1]
+
+
 class _AllReduceMean(torch.autograd.Function):
     """y = mean over ranks of x.  d(loss_total)/dx = mean over ranks of dy (loss_total = mean of rank losses)."""
 
@@ -32,14 +49,14 @@ class _AllReduceMean(torch.autograd.Function):
     def forward(ctx, x):
         import torch.distributed as dist
         y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=_stat_group())
         return y / dist.get_world_size()
 
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
         g = g.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_stat_group())
         return g / dist.get_world_size()
 
 
@@ -103,18 +120,21 @@ class Stepper:
                     self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas, fused=True)
         if distributed and not self.generator.modulewise:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
+        if distributed:
+            _stat_group()          # (created by every rank at the same point)
         self.last = {}
         self._grad_scaler = None      # fp16 activation storage (engine.precision == "fp16"): dynamic loss scaling, created on first use
-        # the two discriminators of the D phase run on two streams (133.4 vs 135.3 ms per iteration); SRK_D_STREAMS=0: one stream.
-        # Single-process runs only: under data parallelism the D losses exchange batch statistics INSIDE their forward / backward
-        # (exact_dp), and collectives issued from side streams gained nothing with RCCL (1 rank: 136.1 vs 136.5 ms) and were
-        # pathologically slow in the two-ranks-on-one-GPU gloo rehearsal.
+        # The two discriminators run on two streams (133.4 vs 135.3 ms per iteration) and the D phase beside the generator's backward
+        # (-1.8 ms): SRK_D_STREAMS=0 / SRK_D_OVERLAP=0 switch them off.  Since round 3 also under data parallelism: the statistic
+        # exchanges inside the D losses are then issued from the discriminator streams, which is legal for the same reason as the
+        # bucket all-reduces of engine._reduce_bucket -- torch.distributed enqueues the collectives of a process group in HOST call
+        # order (identical on every rank) on the group's own stream, whatever stream they were issued from.  SRK_DP_SCHEDULE=serial
+        # keeps a distributed run on one stream (round 2's conservative schedule).
         self._d_streams = None
         self._d_overlap = os.environ.get("SRK_D_OVERLAP", "1") != "0"
-        # (SRK_D_STREAMS=2: also under data parallelism -- the statistic exchanges are then issued from the side streams, in the same
-        # host order on every rank; measured with one rank over RCCL only, NOT verified on several GPUs: opt-in)
         mode = os.environ.get("SRK_D_STREAMS", "1")
-        if (mode == "2" or (mode == "1" and not distributed)) and torch.cuda.is_available() and len(self.discriminators) == 2:
+        dp_serial = distributed and os.environ.get("SRK_DP_SCHEDULE", "overlap") == "serial"
+        if mode != "0" and (mode == "2" or not dp_serial) and torch.cuda.is_available() and len(self.discriminators) == 2:
             self._d_streams = {k: torch.cuda.Stream() for k in self.discriminators}
 
     # ------------------------------------------------------------------ helpers
@@ -133,12 +153,10 @@ class Stepper:
         import torch.distributed as dist
         grads = [p.grad for p in module.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_stat_group())
         flat /= dist.get_world_size()
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        # one multi-tensor copy back (18 tensors per discriminator: 18 launches otherwise, on the path between two host syncs)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
     def _scaler(self):
         """Dynamic loss scaling for the generator's backward when its activations / gradients are stored in fp16 (BASELINE configs[4]):

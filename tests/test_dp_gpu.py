@@ -62,8 +62,9 @@ def _one_iteration(st, lr, hr, eps):
     return out
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, schedule):
     import torch.distributed as dist
+    os.environ["SRK_DP_SCHEDULE"] = schedule          # read when the Stepper / engine are built
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,6 +72,9 @@ def _worker(rank, world, port, outdir):
         torch.cuda.set_device(0)
         st = _stepper(True)
         assert st.generator._engine._sync and st.exact_dp
+        # "overlap" (default since round 3): weight gradients on the side stream with the bucket all-reduces issued from the issue
+        # stream, the two discriminators on two streams, the D phase beside the generator's backward -- all under data parallelism
+        assert st.generator._engine.overlap_wgrad == (schedule == "overlap") and (st._d_streams is not None) == (schedule == "overlap")
         lr, hr, eps = _inputs(world)
         sl = slice(rank * B_RANK, (rank + 1) * B_RANK)
         res = _one_iteration(st, lr[sl].cuda(), hr[sl].cuda(), eps[:, sl].cuda())
@@ -95,12 +99,13 @@ def _rel(a, b):
     return 0.0 if d < 1e-6 else (d / b.abs().max().clamp_min(1e-4)).item()
 
 
-def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("schedule", ["overlap", "serial"])
+def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path, schedule):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn")
-    port = 23000 + (os.getpid() % 4000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    port = 23000 + (os.getpid() % 4000) + (1 if schedule == "serial" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), schedule)) for r in range(world)]
     for p in procs:
         p.start()
     # single process on the whole batch, meanwhile
