@@ -138,6 +138,10 @@ int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* a, size_t* bytes);
  * pixel-splits, so the partial-sum traffic stays small).  The workspace of args[0] is used for all. */
 int srk_conv3x3_wgrad_batched(const srk_wgrad_args* args, int n, void* stream);
 int srk_conv3x3_wgrad_batched_workspace(const srk_wgrad_args* args, int n, size_t* bytes);
+/* n INDEPENDENT weight-gradient problems (any geometries: the layers of a discriminator, models.py:149-174) launched back to back on
+ * `stream` from ONE call; every args[i] carries its own workspace fields (they may all name the same buffer: the launches are
+ * ordered on the stream).  Stops at the first failing launch and returns its status. */
+int srk_conv3x3_wgrad_seq(const srk_wgrad_args* args, int n, void* stream);
 /* Test aid: routing of convolutions with <= 4 channels on one side to the HBM-bound kernels of srk_conv_small.hip:
  * 0 = never, 1 = when their 16x16 tiles fill the chip (default), 2 = whenever the shape allows (small parity cases). */
 int srk_debug_set_conv_small(int mode);

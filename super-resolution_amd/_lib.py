@@ -16,7 +16,7 @@ IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
     "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
-    "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
+    "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_lrelu_grad_mul", "srk_soft_count_fwd", "srk_soft_count_bwd",
@@ -100,6 +100,7 @@ def lib():
         L.srk_conv3x3_wgrad_batched.argtypes = [C.POINTER(WgradArgs), C.c_int, _fp]
         L.srk_conv3x3_wgrad_batched_workspace.argtypes = [C.POINTER(WgradArgs), C.c_int, C.POINTER(C.c_size_t)]
         L.srk_conv3x3_wgrad_kernel_name.argtypes = [C.POINTER(WgradArgs), C.c_int, C.c_char_p, C.c_size_t]
+        L.srk_conv3x3_wgrad_seq.argtypes = [C.POINTER(WgradArgs), C.c_int, _fp]
         L.srk_pack_plan.argtypes = [C.POINTER(PackEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_pack_weights.argtypes = [_fp, C.c_int, C.c_int64, _fp]
         L.srk_pack_weights_bf16x3.argtypes = [_fp, C.c_int, C.c_int64, _fp]
@@ -285,26 +286,54 @@ def _wgrad_kernel_name(arr, n) -> str:
     return buf.value.decode()
 
 
-def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
-                  scale=1.0, accumulate=False, in_slope=1.0, precision=0):
-    a = WgradArgs()
+def _fill_wgrad_args(a, x: View, dy: View, dw: torch.Tensor, db, *, N, H, W, OH, OW, Cin, Cout, stride=1, dy_mode=IN_PLAIN,
+                     scale=1.0, accumulate=False, in_slope=1.0, precision=0):
+    """fills one WgradArgs (all but the workspace fields); returns the workspace bytes the launch needs"""
     a.in_slope = in_slope
     a.precision = precision
     a.N, a.H, a.W, a.OH, a.OW, a.Cin, a.Cout, a.stride, a.dy_mode = N, H, W, OH, OW, Cin, Cout, stride, dy_mode
     a.x, a.x_ldc, a.x_coff = x.t.data_ptr(), x.ldc, x.coff
     a.dy, a.dy_ldc, a.dy_coff = dy.t.data_ptr(), dy.ldc, dy.coff
     a.dw, a.db, a.scale, a.accumulate = dw.data_ptr(), ptr(db), scale, int(accumulate)
-    nbytes = C.c_size_t(0)
-    check(lib().srk_conv3x3_wgrad_workspace(C.byref(a), C.byref(nbytes)), "srk_conv3x3_wgrad_workspace")
-    ws = _workspace(nbytes.value, x.t.device)
+    key = (N, H, W, OH, OW, stride, dy_mode, precision, ((Cin, Cout),), x.ldc, dy.ldc)      # (size by geometry: one query per shape)
+    need = _wgrad_ws_bytes.get(key)
+    if need is None:
+        nbytes = C.c_size_t(0)
+        check(lib().srk_conv3x3_wgrad_workspace(C.byref(a), C.byref(nbytes)), "srk_conv3x3_wgrad_workspace")
+        need = _wgrad_ws_bytes[key] = nbytes.value
+    return need
+
+
+def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, **kw):
+    a = WgradArgs()
+    need = _fill_wgrad_args(a, x, dy, dw, db, **kw)
+    ws = _workspace(need, x.t.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     if KernelTimer.active:
-        e0, e1 = KernelTimer.bracket(_wgrad_kernel_name(C.byref(a), 1) + "+reduce", 2.0 * N * OH * OW * Cout * Cin * 9)
+        e0, e1 = KernelTimer.bracket(_wgrad_kernel_name(C.byref(a), 1) + "+reduce", 2.0 * a.N * a.OH * a.OW * a.Cout * a.Cin * 9)
         e0.record()
         check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
         e1.record()
         return
     check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
+
+
+def conv3x3_wgrad_seq(calls):
+    """``calls``: list of (x, dy, dw, db, kwargs) as for conv3x3_wgrad: independent problems of any geometry (a discriminator's
+    layers) launched back to back by ONE C call (srk_conv3x3_wgrad_seq); one by one while bench.py brackets launches with events."""
+    if KernelTimer.active:
+        for x, dy, dw, db, kw in calls:
+            conv3x3_wgrad(x, dy, dw, db, **kw)
+        return
+    n = len(calls)
+    arr = (WgradArgs * n)()
+    need = 0
+    for a, (x, dy, dw, db, kw) in zip(arr, calls):
+        need = max(need, _fill_wgrad_args(a, x, dy, dw, db, **kw))
+    ws = _workspace(need, calls[0][0].t.device)
+    for a in arr:
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib().srk_conv3x3_wgrad_seq(arr, n, stream_ptr()), "srk_conv3x3_wgrad_seq")
 
 
 def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLAIN, precision=0):

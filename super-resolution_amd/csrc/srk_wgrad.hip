@@ -1190,6 +1190,15 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
   return SRK_OK;
 }
 
+extern "C" int srk_conv3x3_wgrad_seq(const srk_wgrad_args* args, int n, void* stream) {
+  if (!args || n <= 0) return SRK_ERR_BAD_ARG;
+  for (int i = 0; i < n; ++i) {
+    const int rc = srk_conv3x3_wgrad_batched(args + i, 1, stream);
+    if (rc) return rc;
+  }
+  return SRK_OK;
+}
+
 extern "C" int srk_conv3x3_wgrad_workspace(const srk_wgrad_args* pa, size_t* bytes) {
   return srk_conv3x3_wgrad_batched_workspace(pa, 1, bytes);
 }

@@ -229,19 +229,20 @@ class Markovian_Discriminator(nn.Module):
         need_bwd = torch.is_grad_enabled() and (img.requires_grad or any(c.weight.requires_grad for c in convs))
         self._packed.refresh(need_bwd)
         z = ops.to_nhwc(img.float())
-        in_slope = 1.0
-        ci = 0
+        # the whole chain as ONE autograd node: all nine launches of a pass from one library call (ops.ChainPre)
+        meta, wb = [], []
+        in_slope, ci = 1.0, 0
         for m in self.model:
             if isinstance(m, nn.Conv2d):
-                z = ops.conv_pre(z, m.weight, m.bias, m.stride[0], in_slope, self._packed.fwd[ci],
-                                 self._packed.bwd[ci] if need_bwd else None)
+                meta.append((m.stride[0], in_slope, self._packed.fwd[ci], self._packed.bwd[ci] if need_bwd else None))
+                wb += [m.weight, m.bias]
                 ci += 1
                 in_slope = 1.0
             elif isinstance(m, nn.LeakyReLU):
                 in_slope = m.negative_slope        # applied while the next conv stages its input
             else:
                 raise RuntimeError("unexpected layer in Markovian_Discriminator.model")
-        return ops.to_nchw(z)
+        return ops.to_nchw(ops.ChainPre.apply(z, meta, *wb))
 
 
 class Standard_Discriminator(Markovian_Discriminator):

@@ -106,24 +106,29 @@ def conv_pre_raw(x, w, b, stride, in_slope, wp=None):
     return y
 
 
-def conv_dgrad_raw(dz, w, x_or_none, stride, in_slope, H, W, wpt=None):
-    _require_gpu(dz)
-    wpt = wpt if wpt is not None else _pack(w, True)
+def _dgrad_call(dz, w, x_or_none, stride, in_slope, H, W, wpt, dx):
+    """the srk_conv3x3 call (x view, packed weights, bias, y view, kwargs) of one data gradient dx = conv^T(dz, w) * lrelu'(x)"""
     N, OH, OW, Co = dz.shape
     Ci = w.shape[1]
-    dx = torch.empty(N, H, W, Ci, dtype=torch.float32, device=dz.device)
     mask = View(x_or_none) if (x_or_none is not None and in_slope != 1.0) else None
     s2 = getattr(wpt, "s2pack", None)
     if stride == 1:
-        L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=H, W=W, OH=H, OW=W, Cin=Co, Cout=Ci, mask=mask, mask_slope=in_slope)
-    elif s2 is not None and H == 2 * OH and W == 2 * OW:
+        return (View(dz), wpt, None, View(dx), dict(N=N, H=H, W=W, OH=H, OW=W, Cin=Co, Cout=Ci, mask=mask, mask_slope=in_slope))
+    if s2 is not None and H == 2 * OH and W == 2 * OW:
         # stride-2 layer, even extent: conv on dy with 4 * Ci outputs stored through the PixelShuffle epilogue (the mask is read
         # at the shuffled position, i.e. at the dx pixel)
-        L.conv3x3(View(dz), s2[0], None, View(dx), N=N, H=OH, W=OW, OH=OH, OW=OW, Cin=Co, Cout=4 * Ci, ps_out=True,
-                  mask=mask, mask_slope=in_slope, wp_format=s2[1])
-    else:
-        L.conv3x3(View(dz), wpt, None, View(dx), N=N, H=OH, W=OW, OH=H, OW=W, Cin=Co, Cout=Ci,
-                  in_mode=L.IN_ZERO_UPSAMPLE, mask=mask, mask_slope=in_slope)
+        return (View(dz), s2[0], None, View(dx), dict(N=N, H=OH, W=OW, OH=OH, OW=OW, Cin=Co, Cout=4 * Ci, ps_out=True,
+                                                     mask=mask, mask_slope=in_slope, wp_format=s2[1]))
+    return (View(dz), wpt, None, View(dx), dict(N=N, H=OH, W=OW, OH=H, OW=W, Cin=Co, Cout=Ci,
+                                                 in_mode=L.IN_ZERO_UPSAMPLE, mask=mask, mask_slope=in_slope))
+
+
+def conv_dgrad_raw(dz, w, x_or_none, stride, in_slope, H, W, wpt=None):
+    _require_gpu(dz)
+    wpt = wpt if wpt is not None else _pack(w, True)
+    dx = torch.empty(dz.shape[0], H, W, w.shape[1], dtype=torch.float32, device=dz.device)
+    xv, wp, b, yv, kw = _dgrad_call(dz, w, x_or_none, stride, in_slope, H, W, wpt, dx)
+    L.conv3x3(xv, wp, b, yv, **kw)
     return dx
 
 
@@ -156,7 +161,7 @@ class ConvPre(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ConvDgrad.apply(dz, w, x, ctx.stride, ctx.in_slope, ctx.wp, ctx.wpt)
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+        if (not SKIP_PARAM_GRADS) and (ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])):
             dw, db = ConvWgrad.apply(x, dz, ctx.stride, ctx.in_slope)
             if not ctx.has_b:
                 db = None
@@ -217,6 +222,92 @@ class ConvWgrad(torch.autograd.Function):
             elif ggb is not None:
                 g_dz = ggb.view(1, 1, 1, -1).expand_as(dz)
         return g_x, g_dz, None, None
+
+
+# Set by train.Stepper.d_phase_loss around the gradient penalty's INNER torch.autograd.grad(pred_hat, x_hat, create_graph=True)
+# (esrgan.py:602-605): that call wants the input gradient only, but a custom Function's ctx.needs_input_grad is static, so the
+# backward below would also launch every layer's weight gradient and throw it away (18 launches per iteration).
+SKIP_PARAM_GRADS = False
+
+
+class ChainPre(torch.autograd.Function):
+    """z_L = conv_L(lrelu_sL(... conv_1(lrelu_s1(x)) ...)): a whole chain of pre-activation convolutions (the patch discriminator,
+    models.py:149-174) as ONE autograd node whose forward hands all its launches to the library in one call (srk_conv3x3_seq).
+    The backward walks the chain with ConvDgrad / ConvWgrad, the differentiable nodes above, so the gradient penalty's double
+    backward (esrgan.py:596-606) works as before.  (The intermediate pre-activations are saved detached: what ConvPre per layer would
+    add -- a gradient of a WEIGHT gradient w.r.t. the activations of earlier layers -- nothing in the reference's iteration asks for.)
+    ``meta``: per layer (stride, in_slope, packed forward weights, packed data-gradient weights or None); ``wb``: w_1, b_1, w_2, ..."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *wb):
+        _require_gpu(x)
+        x = x.contiguous()
+        ctx.set_materialize_grads(False)
+        n_l = len(meta)
+        zs, calls = [x], []
+        N, H, W, Ci = x.shape
+        for l, (stride, in_slope, wp, _) in enumerate(meta):
+            w, b = wb[2 * l], wb[2 * l + 1]
+            Co = w.shape[0]
+            OH, OW = _out_hw(H, W, stride)
+            y = torch.empty(N, OH, OW, Co, dtype=torch.float32, device=x.device)
+            calls.append((View(zs[-1]), wp if wp is not None else _pack(w, False), None if b is None else b.detach().contiguous(), View(y),
+                          dict(N=N, H=H, W=W, OH=OH, OW=OW, Cin=Ci, Cout=Co, stride=stride, in_slope=in_slope)))
+            zs.append(y)
+            H, W, Ci = OH, OW, Co
+        L.conv3x3_seq(calls)
+        ctx.meta = meta
+        ctx.save_for_backward(*zs[:-1], *[wb[2 * l] for l in range(n_l)])
+        ctx.has_b = [wb[2 * l + 1] is not None for l in range(n_l)]
+        return zs[-1]
+
+    @staticmethod
+    def backward(ctx, dz):
+        n_l = len(ctx.meta)
+        if dz is None:
+            return (None,) * (2 + 2 * n_l)
+        saved = ctx.saved_tensors
+        zs, ws = saved[:n_l], saved[n_l:]
+        dz = dz.contiguous()
+        grads = [None] * (2 * n_l)
+        want_w = [(not SKIP_PARAM_GRADS) and (ctx.needs_input_grad[2 + 2 * l] or (ctx.has_b[l] and ctx.needs_input_grad[3 + 2 * l]))
+                  for l in range(n_l)]
+        if not torch.is_grad_enabled():
+            # first-order backward (nothing will differentiate THIS pass): no autograd nodes needed, so the whole chain of data
+            # gradients goes to the library in one call and all weight gradients in a second one
+            _require_gpu(dz)
+            dzs, calls = [None] * n_l + [dz], []
+            first = 0 if ctx.needs_input_grad[0] else 1
+            for l in range(n_l - 1, first - 1, -1):
+                stride, in_slope, wp, wpt = ctx.meta[l]
+                _, H, W, Ci = zs[l].shape
+                dzs[l] = torch.empty(zs[l].shape, dtype=torch.float32, device=dz.device)
+                calls.append(_dgrad_call(dzs[l + 1], ws[l], zs[l], stride, in_slope, H, W, wpt if wpt is not None else _pack(ws[l], True), dzs[l]))
+            if calls:
+                L.conv3x3_seq(calls)
+            wcalls = []
+            for l in range(n_l):
+                if want_w[l]:
+                    stride, in_slope, _, _ = ctx.meta[l]
+                    Co, Ci = ws[l].shape[:2]
+                    dw = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device=dz.device)
+                    db = torch.empty(Co, dtype=torch.float32, device=dz.device) if ctx.has_b[l] else None
+                    N, H, W, _ = zs[l].shape
+                    _, OH, OW, _ = dzs[l + 1].shape
+                    wcalls.append((View(zs[l]), View(dzs[l + 1]), dw, db, dict(N=N, H=H, W=W, OH=OH, OW=OW, Cin=Ci, Cout=Co, stride=stride,
+                                                                              in_slope=in_slope)))
+                    grads[2 * l], grads[2 * l + 1] = dw, db
+            if wcalls:
+                L.conv3x3_wgrad_seq(wcalls)
+            return (dzs[0] if ctx.needs_input_grad[0] else None, None) + tuple(grads)
+        for l in range(n_l - 1, -1, -1):
+            stride, in_slope, wp, wpt = ctx.meta[l]
+            if want_w[l]:
+                dw, db = ConvWgrad.apply(zs[l], dz, stride, in_slope)
+                grads[2 * l], grads[2 * l + 1] = dw, (db if ctx.has_b[l] else None)
+            if l > 0 or ctx.needs_input_grad[0]:
+                dz = ConvDgrad.apply(dz, ws[l], zs[l], stride, in_slope, wp, wpt)
+        return (dz if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
 def conv_pre(x, w, b, stride=1, in_slope=1.0, wp=None, wpt=None):
