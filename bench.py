@@ -320,7 +320,8 @@ def main():
         if os.path.exists(tpath):
             try:   # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                 # same command (tools/traffic_from_pmc.py; FETCH_SIZE x2 on gfx950), not collectable in-process
-                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))          # (rocprofv3 does not demangle the _Float16 kernels: those are keyed by base name)
+                traffic = (tj.get(name) or tj.get(name.split("<")[0]) or {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_source = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command on an earlier box (PMC counters cannot be read in-process); not measured in this run")
