@@ -224,6 +224,15 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     }
   };
 
+  // The stage barrier's counted wait: vector-memory operations retire in order, and behind the last DMA piece of chunk q + 1 a wave
+  // has issued exactly the weight loads of ONE phase (6 column positions x 2 channel halves, the LB phase (2,0) resp. (2)), so
+  // "all but the W42_LB_PER_PHASE youngest" = every DMA piece of the next chunk has landed.  The literal in the asm below is this
+  // constant (static_assert), and tools/check_w42_hazards.py checks the same statement in the disassembly of the shipped object.
+  constexpr int W42_LB_PER_PHASE = 6 * 2;
+  static_assert(W42_LB_PER_PHASE == 12, "the s_waitcnt vmcnt(12) in front of the stage barrier counts one phase of weight loads");
+#define W42_STR2(x) #x
+#define W42_STR(x) W42_STR2(x)
+#define W42_WAIT_PIECES() asm volatile("s_waitcnt vmcnt(" W42_STR(12) ")" ::: "memory")
   W42_SEG_BEGIN();
   // Chunk q sits in buffer b:  (e, mt) = (0,0) (1,0) | (0,1) (1,1) | (2,0) (3,0) | (2,1) | barrier | (3,1)
   //   weights: P1 <- pair 1 of chunk q during (0,0), P0 <- pair 0 of chunk q + 1 during (2,0): four phases ahead of their use
@@ -238,7 +247,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
       phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
       phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
       phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      W42_WAIT_PIECES();
       __syncthreads();
       phase(I0{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
     } else {
@@ -257,7 +266,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     phase(I1{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, No{}, 0, 0, P0, IN{}, 0, Bc{});
     W42_SEG(6);
     // vector-memory operations retire in order: all but the 12 weight loads of (2,0) = every DMA piece of chunk q + 1
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    W42_WAIT_PIECES();
     __syncthreads();
     W42_SEG(7);
     phase(I1{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)

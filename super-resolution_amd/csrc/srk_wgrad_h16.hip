@@ -166,32 +166,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
     if (tile + 1 < t_end) stage(tile + 1, b ^ 1);
     const char* buf = reinterpret_cast<const char*>(smem + b * HT_STAGE4);
     if (active) {
+      // Fragments are read AHEAD by hand (sched_barrier between the slots): left to the compiler every x fragment was read right in
+      // front of the MFMAs that use it (read, wait, 1-3 MFMAs: the LDS latency of 30 fragments per tile on top of 80 MFMAs).
       v8 af[HT_H];
+      auto rdB = [&](int i) {                      // x fragment of step i = HT_IW-row ri, column shift s (i = s * (HT_H + 2) + ri)
+        const int s = i / (HT_H + 2), ri = i % (HT_H + 2);
+        const char* base = buf + b_lane + (ri * HT_IW + s) * 64;
+        const v4 h0 = wh_tr_read<T>(base), h1 = wh_tr_read<T>(base + 4 * 64);
+        v8 bf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bf[j] = h0[j]; bf[4 + j] = h1[j]; }
+        return bf;
+      };
+      constexpr int NSTEP = 3 * (HT_H + 2), AHEAD = 3;
+      v8 bring[4];
 #pragma unroll
       for (int kk = 0; kk < HT_H; ++kk) {
         const v4 h0 = wh_tr_read<T>(buf + a_lane + (16 * kk) * 64), h1 = wh_tr_read<T>(buf + a_lane + (16 * kk + 4) * 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { af[kk][j] = h0[j]; af[kk][4 + j] = h1[j]; }
       }
+#pragma unroll
+      for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
+      __builtin_amdgcn_sched_barrier(0);
       if (do_bias) {
 #pragma unroll
         for (int kk = 0; kk < HT_H; ++kk) accb = WH<T>::mfma(af[kk], ones, accb);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int i = 0; i < NSTEP; ++i) {
+        const int s = i / (HT_H + 2), ri = i % (HT_H + 2);
+        if (i + AHEAD < NSTEP) bring[(i + AHEAD) & 3] = rdB(i + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ri = 0; ri < HT_H + 2; ++ri) {
-          const char* base = buf + b_lane + (ri * HT_IW + s) * 64;
-          const v4 h0 = wh_tr_read<T>(base), h1 = wh_tr_read<T>(base + 4 * 64);
-          v8 bf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { bf[j] = h0[j]; bf[4 + j] = h1[j]; }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int kk = ri - r;
-            if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bf, acc[3 * r + s]);
-          }
+        for (int r = 0; r < 3; ++r) {
+          const int kk = ri - r;
+          if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & 3], acc[3 * r + s]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 

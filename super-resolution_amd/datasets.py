@@ -120,8 +120,19 @@ class SparseJetDataset(_RowDataset):
 
     def __init__(self, rows, amount=None, etaBins=80, phiBins=80, factor=2, pre_factor=1, threshold=None, N=None, noise_factor=None):
         super().__init__(rows, amount, etaBins, phiBins, factor, pre_factor, threshold, N)
-        if noise_factor is not None:
-            raise NotImplementedError("noise_factor (host-side numpy RNG in the reference, datasets.py:238-244) is not implemented")
+        self.noise_factor = noise_factor
+        self.noise_pixels = 150          # datasets.py:241-242: all but 150 randomly chosen noise pixels are zeroed
+
+    @staticmethod
+    def add_noise(img, noise, keep, noise_factor):
+        """datasets.py:238-244 for a whole batch, given the random draws: ``noise`` = randn of img's shape, ``keep`` [B, n] = the flat
+        pixel indices of each image whose noise survives.  noise <- |noise| / (noise_factor * max |noise| of the image), zero outside
+        ``keep``, added to the image."""
+        b = img.shape[0]
+        a = noise.abs().reshape(b, -1)
+        a = a / (noise_factor * a.max(dim=1, keepdim=True).values)
+        sparse = torch.zeros_like(a).scatter_(1, keep, a.gather(1, keep))
+        return img + sparse.view_as(img)
 
     def decode_batch(self, rows):
         """rows: [B, row_len] on the GPU -> {"lr": [B,1,h,w], "hr": [B,1,H,W]}."""
@@ -130,6 +141,13 @@ class SparseJetDataset(_RowDataset):
                             threshold=self.threshold if not self.N else None, n_pairs=n_pairs)
         if self.N:
             img = self.cutter(img)
+        if self.noise_factor is not None:
+            # the reference draws on the host (torch.randn + np.random.choice); here the whole batch is drawn on the GPU: per image
+            # |N(0,1)| noise, scaled to a maximum of 1 / noise_factor, on 150 pixels chosen uniformly without replacement
+            b, npx = img.shape[0], img[0].numel()
+            noise = torch.randn(img.shape, device=img.device)
+            keep = torch.rand(b, npx, device=img.device).topk(min(self.noise_pixels, npx), dim=1).indices
+            img = self.add_noise(img, noise, keep, float(self.noise_factor))
         return self._finish(img)
 
 

@@ -119,11 +119,33 @@ def _opt_dict(opt):
         return dict(vars(opt))
 
 
+# keys other tools of the reference add to the option set they pass around (hyper_search.py:104,159; info.json bookkeeping):
+# carried along silently
+FOREIGN_OK = ("n_histograms", "hyper_search", "seed", "default", "name_", "gpu", "synthetic_batches", "dataset", "precision")
+_warned = set()
+
+
+def _warn_once(msg):
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0 and msg not in _warned:
+        _warned.add(msg)
+        print("[super-resolution_amd] warning: " + msg, flush=True)
+
+
 def _complete(opt):
     """Namespace carrying every option this module reads: the caller's values over DEFAULTS (a namedtuple built from a json of
-    a few options, as constant_args.json + hyper_search.py produce, lacks the rest)."""
+    a few options, as constant_args.json + hyper_search.py produce, lacks the rest).  Keys that are neither options of the
+    reference nor known bookkeeping keys are kept but reported once (a misspelt `lamda_hist` would otherwise train with the
+    default, silently), and so are options of the IGNORED list that were given a non-default value."""
     d = dict(DEFAULTS)
-    d.update(_opt_dict(opt))
+    given = _opt_dict(opt)
+    for k, v in given.items():
+        if k not in DEFAULTS and k not in FOREIGN_OK:
+            _warn_once(f"unknown option '{k}' is carried along but has no effect here (misspelt?)")
+        elif k in IGNORED and v != DEFAULTS[k]:
+            _warn_once(f"option '{k}' = {v!r} is accepted for compatibility and ignored (it steers the reference's validation / "
+                       "evaluation / plotting scaffolding, outside this build's scope)")
+    d.update(given)
     return SimpleNamespace(**d)
 
 

@@ -77,3 +77,37 @@ def test_decode_fails_loudly(DS):
         DS.extract_batch(torch.zeros(2, 9), 4, 4)
     with pytest.raises(RuntimeError):
         DS.extract_batch(torch.zeros(2, 2 * 5000 + 1, device="cuda"), 4, 4)     # > 4096 pairs: unsupported
+
+
+def test_sparse_jet_noise_factor(DS):
+    """SparseJetDataset(noise_factor=...) (datasets.py:238-244): |N(0,1)| noise scaled to a per-image maximum of 1 / noise_factor on
+    150 randomly kept pixels, added before the pre-pool / LR pooling.  The arithmetic given the draws is checked against a numpy
+    restatement of the reference lines; the draws themselves (the reference makes them on the host) statistically."""
+    rng = np.random.RandomState(3)
+    B, eta, phi, L = 5, 40, 40, 30
+    rows = np.zeros((B, 2 * L + 1), dtype=np.float32)
+    for b in range(B):
+        n = rng.randint(5, L)
+        rows[b, 0:2 * n:2] = rng.randint(0, eta * phi, size=n)
+        rows[b, 1:2 * n:2] = rng.rand(n) * 10 + 0.1
+    plain = DS.SparseJetDataset(rows, etaBins=eta, phiBins=phi, factor=2)
+    noisy = DS.SparseJetDataset(rows, etaBins=eta, phiBins=phi, factor=2, noise_factor=4.0)
+    batch = torch.from_numpy(rows).cuda()
+    base = plain.decode_batch(batch)["hr"]
+    # deterministic part vs numpy (datasets.py:239-244 with the draws handed in)
+    noise = torch.randn(base.shape, generator=torch.Generator().manual_seed(1))
+    keep = torch.stack([torch.randperm(eta * phi, generator=torch.Generator().manual_seed(10 + b))[:150] for b in range(B)])
+    got = DS.SparseJetDataset.add_noise(base, noise.cuda(), keep.cuda(), 4.0).cpu()
+    for b in range(B):
+        nz = np.abs(noise[b].numpy())
+        nz = nz / (4.0 * nz.max())
+        m = np.zeros(nz.size, dtype=bool); m[keep[b].numpy()] = True
+        nz = np.where(m.reshape(nz.shape), nz, 0.0)
+        assert np.allclose(got[b].numpy(), base[b].cpu().numpy() + nz, rtol=0, atol=1e-6)
+    # the dataset's own draws
+    out = noisy.decode_batch(batch)
+    d = (out["hr"] - base).cpu()
+    assert (d >= 0).all() and d.max().item() <= 0.25 + 1e-6
+    assert all(int((d[b] > 0).sum()) in range(140, 151) for b in range(B))          # 150 kept pixels (|noise| > 0 almost surely)
+    assert torch.allclose(out["lr"], torch.nn.functional.avg_pool2d(out["hr"], 2) * 4, atol=1e-5)
+    assert not torch.equal(noisy.decode_batch(batch)["hr"], out["hr"])              # fresh draws per batch

@@ -1,6 +1,7 @@
 """CPU: host-side logic of the drop-in (no kernel launches): class surface, state_dict contract, C-ABI exports,
 loud failure without a GPU, and the world-size-2 data-parallel plumbing on gloo."""
 import ctypes
+import importlib
 import os
 import re
 import sys
@@ -327,9 +328,22 @@ def test_transposed_conv_variants_keep_the_reference_state_dict(srk, golden_dir)
 
 def test_inline_asm_mfma_hazards_of_the_wino42_kernel():
     """The F(2x4,3x3) conv kernel issues its MFMAs as inline assembly (register classes spelled out), which the compiler's
-    hazard recogniser does not see: the generated code must keep two wait states between a VALU write and an MFMA read."""
+    hazard recogniser does not see: the code of the SHIPPED object must keep two wait states between a VALU write and an MFMA
+    read, and its hand-counted `s_waitcnt vmcnt(12)` must sit behind exactly [halo DMA piece, 12 weight loads]."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_w42_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 hazard(s)" in r.stdout
+    assert "0 violation(s)" in r.stdout and "864 v_mfma" in r.stdout
+
+
+def test_unknown_and_ignored_options_are_reported_once(capsys):
+    """A misspelt option must not silently train with the default; an IGNORED option given a value says that it is ignored."""
+    es = importlib.import_module("super-resolution_amd.esrgan")
+    es._warned.clear()
+    o = es._complete(es.options(lamda_hist=0.5, n_cpu=4, n_histograms=3))
+    assert o.lamda_hist == 0.5 and o.lambda_hist == es.DEFAULTS["lambda_hist"]
+    out = capsys.readouterr().out
+    assert "unknown option 'lamda_hist'" in out and "option 'n_cpu' = 4" in out and "n_histograms" not in out
+    es._complete(es.options(lamda_hist=0.5))
+    assert capsys.readouterr().out == ""          # once

@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""Build-time lint for srk_conv_w42.hip: its MFMAs are inline assembly, which the compiler's hazard recogniser does not see.
-gfx950 needs two wait states between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB; this script compiles the
-file to assembly and checks that no v_mfma in the wino42 kernels reads a register that one of the two preceding instructions
-wrote (VALU destinations only: loads are covered by s_waitcnt, which the compiler does insert for inline-asm operands).
-Exit status 1 on a violation.  Usage: python tools/check_w42_hazards.py [--keep]"""
-import os, re, subprocess, sys, tempfile
+"""Build-time lint for srk_conv_w42.hip, run on the OBJECT THAT IS LINKED INTO libsrk.so (build/srk_conv_w42.o: the device code is
+extracted with llvm-objdump --offloading and disassembled), so the flags checked are the flags shipped.
+
+1. The kernel's MFMAs are inline assembly, which the compiler's hazard recogniser does not see.  gfx950 needs two wait states
+   between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB: no v_mfma in the wino42 kernels may read a register
+   that one of the two preceding instructions wrote (VALU destinations only: loads are covered by s_waitcnt, which the compiler
+   does insert for inline-asm operands).  The window is reset at branches and at symbols.
+2. The stage barrier's hand-written `s_waitcnt vmcnt(12)` encodes a count of vector-memory operations in flight: the 12 youngest
+   ones must be the weight loads of one phase (buffer_load_dwordx2), and the next older one a halo DMA piece (buffer_load ... lds)
+   -- i.e. "all but the 12 youngest" retires exactly every DMA piece of the next chunk.  A schedule edit that changes the count
+   fails here instead of racing on the GPU.
+Exit status 1 on a violation.  Usage: python tools/check_w42_hazards.py [object file]"""
+import os, re, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "super-resolution_amd", "csrc", "srk_conv_w42.hip")
+OBJ = os.path.join(ROOT, "super-resolution_amd", "csrc", "build", "srk_conv_w42.o")
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
 
 
 def regs(tok):
@@ -21,50 +29,84 @@ def regs(tok):
     return set()
 
 
-def main():
-    out = os.path.join(tempfile.mkdtemp(), "w42.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
-           SRC, "-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+def disassemble(obj):
+    tmp = tempfile.mkdtemp()
+    local = os.path.join(tmp, "w42.o")
+    shutil.copy(obj, local)
+    r = subprocess.run([OBJDUMP, "--offloading", local], capture_output=True, text=True)
+    dev = [f for f in os.listdir(tmp) if "amdgcn" in f]
+    if r.returncode or not dev:
+        sys.stderr.write(r.stdout + r.stderr + "\nno device code object in %s\n" % obj)
+        return None
+    r = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, dev[0])], capture_output=True, text=True)
     if r.returncode:
         sys.stderr.write(r.stderr)
+        return None
+    return r.stdout
+
+
+def main():
+    obj = sys.argv[1] if len(sys.argv) > 1 else OBJ
+    if not os.path.exists(obj):
+        sys.stderr.write("%s not found: build the library first (make -C super-resolution_amd/csrc)\n" % obj)
         return 2
-    bad = total = 0
+    text = disassemble(obj)
+    if text is None:
+        return 2
+    bad = total = waits_checked = 0
     inside = False
     prev = []          # the last two real instructions: (mnemonic, dst registers)
-    for line in open(out):
-        t = line.strip()
-        if re.match(r"_ZN.*wino42_kernel.*:", t):
-            inside, prev = True, []
+    vmem = []          # vector-memory instructions of the current kernel in program order
+    last_wait = None   # the s_waitcnt ... vmcnt(N) directly in front of the current instruction, if any
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            inside = "wino42_kernel" in m.group(1)
+            prev, vmem, last_wait = [], [], None
             continue
-        if not inside or not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
-            if inside and t.startswith(".Lfunc_end"):
-                inside = False
+        if not inside:
             continue
-        t = t.split(";")[0].strip()
+        t = line.split("//")[0].strip()
         if not t:
             continue
         parts = t.replace(",", " ").split()
         mn, ops = parts[0], parts[1:]
+        if mn.startswith("s_cbranch") or mn == "s_branch" or mn == "s_endpgm":
+            prev = []
+            continue
+        if mn.startswith("buffer_") or mn.startswith("global_") or mn.startswith("flat_"):
+            vmem.append(t)
+        if mn == "s_barrier" and last_wait is not None:
+            # the stage barrier: the hand-written counted wait sits directly in front of it (the compiler's own vmcnt waits, in
+            # front of the first use of a loaded register, are not followed by a barrier)
+            waits_checked += 1
+            n = int(re.search(r"vmcnt\((\d+)\)", last_wait).group(1))
+            young, older = vmem[-n:] if n else [], vmem[-n - 1:len(vmem) - n]
+            ok = len(young) == n and all(v.startswith("buffer_load_dwordx2") and " lds" not in v for v in young) and \
+                len(older) == 1 and " lds" in older[0]
+            if n and not ok:
+                bad += 1
+                print("VMCNT: `%s` + s_barrier does not sit behind [halo DMA piece, %d weight loads]; last vector-memory ops: %s"
+                      % (last_wait, n, [v.split()[0] + (" lds" if " lds" in v else "") for v in vmem[-n - 1:]]))
+        last_wait = t if re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", t) and not t.endswith("(0)") else None     # (counted, vmcnt only)
         if mn.startswith("v_mfma"):
             total += 1
             src = regs(ops[1]) | regs(ops[2])
             for k, (pm, pd) in enumerate(reversed(prev)):
                 if pm.startswith("v_") and not pm.startswith("v_mfma") and (pd & src):
-                    # an s_nop N in between provides N + 1 wait states
                     bad += 1
                     print("HAZARD: %s reads v%s written %d instruction(s) earlier by %s" % (t, sorted(pd & src), k + 1, pm))
         waits = 0
         if mn == "s_nop":
-            waits = int(ops[0]) + 1
+            waits = int(ops[0]) + 1          # an s_nop N provides N + 1 wait states
         dst = regs(ops[0]) if (ops and mn.startswith("v_") and not mn.startswith("v_cmp")) else set()
         if waits >= 2:
             prev = []
         else:
             prev = (prev + [(mn, dst)])[-2:]
-    print("checked %d v_mfma instructions in the wino42 kernels: %d hazard(s)" % (total, bad))
-    return 1 if bad or total == 0 else 0
+    print("checked %d v_mfma instructions and %d counted vmcnt waits in the wino42 kernels of %s: %d violation(s)"
+          % (total, waits_checked, os.path.relpath(obj, ROOT), bad))
+    return 1 if bad or total == 0 or waits_checked == 0 else 0
 
 
 if __name__ == "__main__":
