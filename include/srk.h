@@ -202,7 +202,8 @@ size_t srk_packed_floats_wino(int K, int M);   /* fmt 3: 12 transformed taps ins
 size_t srk_packed_floats_wino4(int K, int M);  /* fmt 5: 18 transformed taps */
 size_t srk_packed_floats_wino42(int K, int M); /* fmt 6: 24 transformed taps */
 size_t srk_packed_floats_h16(int K, int M);    /* fmt 7 / 8: size of the 16-bit fragment buffer in FLOAT units (4 bytes) */
-/* Test aid: rows per wave of the 16-bit-storage conv kernel (wp_format 7 / 8): 0 = by launch size (default), 2 = 8-row tiles, 4 = 16-row tiles */
+/* Rows per wave of the 16-bit-storage conv kernel (wp_format 7 / 8): 0 = by launch size (default), 2 = 8-row tiles, 4 = 16-row tiles,
+ * 1 = the shared-CU form (8-row tiles, 16-channel stages, two workgroups per CU: the engine's two-chain mode selects it) */
 int srk_debug_set_h16_mt(int mt);
 /* 1 if srk_conv3x3 accepts wp_format == 1 for this geometry (stride 1, Cin % 16 == 0, 16-byte addressable input) */
 int srk_conv3x3_bf16x3_supported(const srk_conv_args* a);

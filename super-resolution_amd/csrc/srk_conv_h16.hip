@@ -472,6 +472,192 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ the shared-CU form ("h16s")
+// The kernel above owns its CU (152 KB of LDS): the ~12 us of every launch that are memory bursts and the kernel boundary -- first
+// stage arriving on all CUs at once, 16.8 MB of stores at the end -- overlap with nothing.  This form is built so that TWO
+// workgroups share a CU (58 KB of LDS, <= 256 registers, 4 waves): 8 x 32-pixel tiles, 16-channel stages (pixel-major halo image
+// of 32 bytes per pixel, slot j of pixel p holds the 8-channel group j ^ ((p >> 3) & 1): conflict-free ds_read_b128 over any 16
+// consecutive pixels), the MFMA waves issue their own DMA pieces (what that costs them the co-resident workgroup fills with its
+// MFMAs).  It pays when the two workgroups of a CU are at DIFFERENT points of their launches: the engine's two-chain mode runs
+// the batch halves as two dependency chains on two streams, so that one chain's bursts sit beside the other chain's main loop.
+template <typename T, int MODE, bool OUTF32>
+__global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_args a) {
+  typedef typename H16<T>::v8 v8;
+  constexpr int MT = 2, TH = 4 * MT, IH = TH + 2, NHP = IH * HW_IW;          // 340 halo pixels
+  constexpr int HPIECES = (2 * NHP + 63) / 64, WPIECES = 18;                  // 11 + 18 one-KB pieces per 16-channel stage
+  constexpr int STAGE4 = (HPIECES + WPIECES + 1) * 64, WBASE = HPIECES * 64, DUMMY = (HPIECES + WPIECES) * 64;
+  constexpr int NJH = (HPIECES + 3) / 4, NJW = (WPIECES + 3) / 4, NPIECE = NJH + NJW;
+  constexpr int SMEM4 = 2 * STAGE4 > 2048 ? 2 * STAGE4 : 2048;
+  __shared__ float4 smem[SMEM4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int tilesW = (a.OW + HW_TW - 1) / HW_TW, tilesH = (a.OH + TH - 1) / TH;
+  int bid = blockIdx.x;
+  {
+    const int Tn = gridDim.x;
+    if ((Tn & 7) == 0) bid = (bid & 7) * (Tn >> 3) + (bid >> 3);
+  }
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * TH, ow0 = tx * HW_TW, n0 = blockIdx.y * 64;
+  const int CoutP = (a.Cout + 63) & ~63;
+  const int nq = a.Cin >> 4;                          // stages of 16 input channels
+
+  const T* xbase = reinterpret_cast<const T*>(a.x);
+  const int Cps_in = a.Cin >> 2;
+  long img_elems = (long)a.H * a.W * a.x_ldc;
+  if (MODE == SRK_IN_UNSHUFFLE) img_elems *= 4;
+  const T* ximg = xbase + (long)n * img_elems;
+  const unsigned xbytes = (unsigned)(img_elems * 2);
+  const unsigned wbytes = (unsigned)((long)nq * 18 * CoutP * 16);
+  unsigned xvo[NJH];
+#pragma unroll
+  for (int j = 0; j < NJH; ++j) {
+    const int hp = (wv + 4 * j) * 32 + (lane >> 1);                       // halo pixel of this lane in piece wv + 4 j
+    const int g = (lane & 1) ^ ((hp >> 3) & 1);                           // the 8-channel group its slot holds
+    const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
+    const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+    unsigned off;
+    if (MODE == SRK_IN_UNSHUFFLE) off = (unsigned)((2 * ih) * (2 * a.W) + 2 * iw) * (unsigned)a.x_ldc + (unsigned)(a.x_coff + 8 * g);
+    else off = (unsigned)(ih * a.W + iw) * (unsigned)a.x_ldc + (unsigned)(a.x_coff + 8 * g);
+    const bool ok = hp < NHP && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    xvo[j] = ok ? off * 2u : H_OOB;
+  }
+  const unsigned wvo = (unsigned)((n0 + lane) * 16);
+  // piece j of stage qs (newest channels first, as above) into buffer b; a piece that does not exist goes through a zero-record
+  // descriptor into the DUMMY slot (no branch in the main loop)
+  auto piece = [&](int qs, auto bc, auto jc) {
+    constexpr int b = decltype(bc)::value, j = decltype(jc)::value;
+    float4* dst = smem + b * STAGE4;
+    const int q = nq - 1 - qs;
+    if constexpr (j < NJH) {
+      unsigned xso = (unsigned)(16 * q * 2);
+      if (MODE == SRK_IN_UNSHUFFLE) {
+        const int c16 = 16 * q;
+        const int ij = c16 / Cps_in, c = c16 - ij * Cps_in;
+        xso = (unsigned)(((long)(ij >> 1) * (2 * a.W) * a.x_ldc + (long)(ij & 1) * a.x_ldc + c) * 2);
+      }
+      const int i = wv + 4 * j;
+      const bool live = qs < nq && i < HPIECES;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, live ? xbytes : 0u, 0x00020000);
+      h16_dma(rs, dst + (i < HPIECES ? i * 64 : DUMMY), xvo[j], live ? xso : 0u);
+    } else {
+      const int w = wv + 4 * (j - NJH);
+      const bool live = qs < nq && w < WPIECES;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, live ? wbytes : 0u, 0x00020000);
+      h16_dma(rs, dst + (w < WPIECES ? WBASE + w * 64 : DUMMY), wvo, live ? (unsigned)((q * 18 + w) * CoutP * 16) : 0u);
+    }
+  };
+
+  f32x16 acc[MT][2];
+  constexpr int SPS = MT + 2, STEPS = 3 * SPS;                    // 12 steps per stage: column shift s, halo row ri
+  int aaddr[STEPS];
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+    const int s = i / SPS, ri = i % SPS;
+    const int hp = (MT * wv + ri) * HW_IW + l32 + s;
+    aaddr[i] = hp * 32 + (hl ^ ((hp >> 3) & 1)) * 16;
+  }
+  const int baddr = (WBASE + hl * 64 + l32) * 16;                 // + ((tap * 2) * 64 + 32 t) * 16
+  constexpr int DEFER = 4, AHEAD = 4;
+  constexpr int RINGP = STEPS & 7;                                // 4: the ring closes over a pair of stages
+  static_assert(NPIECE <= STEPS - DEFER && ((2 * STEPS) & 7) == 0, "one DMA piece per step; the A ring must close over a pair of stages");
+  v8 Af[8], Bf[2][3][2];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  const char* sm = reinterpret_cast<const char*>(smem);
+  auto rdA = [&](int P, int L) { return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + P * (STAGE4 * 16) + aaddr[L])); };
+  auto rdB = [&](int P, int s, int r, int t) {
+    return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + P * (STAGE4 * 16) + baddr + (((3 * r + s) * 2) * 64 + 32 * t) * 16));
+  };
+  auto mfma_step = [&](auto pc, auto lc) {
+    constexpr int P = decltype(pc)::value, L = decltype(lc)::value;
+    constexpr int s = L / SPS, ri = L % SPS;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int m = ri - r;
+      if (m >= 0 && m < MT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[(RINGP * P + L) & 7], Bf[(P + s) & 1][r][t], acc[m][t]);
+      }
+    }
+  };
+  auto head = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) Bf[P & 1][r][t] = rdB(P, 0, r, t);
+#pragma unroll
+    for (int L = 0; L < AHEAD; ++L) Af[(RINGP * P + L) & 7] = rdA(P, L);
+  };
+  auto stage_fn = [&](int qs, auto pc) {
+    constexpr int P = decltype(pc)::value;
+    using Pc = std::integral_constant<int, P>; using Pn = std::integral_constant<int, P ^ 1>;
+    auto step = [&](auto lc) {
+      constexpr int L = decltype(lc)::value;
+      constexpr int s = L / SPS, ri = L % SPS;
+      if constexpr (L + AHEAD < STEPS) Af[(RINGP * P + L + AHEAD) & 7] = rdA(P, L + AHEAD);
+      if constexpr (ri >= 1 && ri <= 3 && s < 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) Bf[(P + s + 1) & 1][ri - 1][t] = rdB(P, s + 1, ri - 1, t);
+      }
+      if constexpr (L + 2 < NPIECE) piece(qs + 1, Pn{}, std::integral_constant<int, (L + 2 < NPIECE ? L + 2 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(Pc{}, lc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - DEFER>{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    head(Pn{});
+    piece(qs + 2, Pc{}, I0{});
+    piece(qs + 2, Pc{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (mfma_step(Pc{}, std::integral_constant<int, STEPS - DEFER + Ls>{}), ...); }(std::make_integer_sequence<int, DEFER>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // (weights first: their addresses need no arithmetic)
+  [&]<int... Js>(std::integer_sequence<int, Js...>) { (piece(0, I0{}, std::integral_constant<int, NJH + Js>{}), ...); }(std::make_integer_sequence<int, NJW>{});
+  [&]<int... Js>(std::integer_sequence<int, Js...>) { (piece(0, I0{}, std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, NJH>{});
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  head(I0{});
+  piece(1, I1{}, I0{});
+  piece(1, I1{}, I1{});
+  {
+    int q = 0;
+    for (; q + 1 < nq; q += 2) {
+      stage_fn(q, I0{});
+      stage_fn(q + 1, I1{});
+    }
+    if (q < nq) stage_fn(q, I0{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (empty) pieces: their zeros must have landed
+  __builtin_amdgcn_s_barrier();                                      // before any wave reuses the staging buffers
+  float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
+  const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
+  if constexpr (OUTF32) {
+    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+  } else {
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else h16_epilogue<T, MT, 3, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight packing (formats 7 / 8)
 // dst[q16][tap][h][Mp64][8] of T, k = 16 q + 8 h + e.  Work item = one (q, tap, h, m): 8 consecutive k, one 16-byte store.
 template <typename T>
@@ -525,10 +711,23 @@ int g_h16_mt = -1;
     else hipLaunchKernelGGL((conv3x3_h16_kernel<T, MODE, MT, false>), grid, dim3(H16_THREADS), 0, st, a);                      \
   } while (0)
 
+#define H16S_LAUNCH(T, MODE)                                                                                           \
+  do {                                                                                                                 \
+    if (a.flags & SRK_CONV_OUT_F32) hipLaunchKernelGGL((conv3x3_h16s_kernel<T, MODE, true>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((conv3x3_h16s_kernel<T, MODE, false>), grid, dim3(256), 0, st, a);                         \
+  } while (0)
+
 int launch_h16_any(const srk_conv_args& a, int mt, hipStream_t st) {
+  const bool un = a.in_mode == SRK_IN_UNSHUFFLE;
+  if (mt == 1) {          // the shared-CU form: 8-row tiles, two workgroups per CU
+    dim3 grid((unsigned)(a.N * srk_div_up(a.OH, 8) * srk_div_up(a.OW, HW_TW)), (unsigned)(srk_round_up(a.Cout, 64) / 64));
+    if (a.wp_format == 7) { if (un) H16S_LAUNCH(_Float16, 1); else H16S_LAUNCH(_Float16, 0); }
+    else { if (un) H16S_LAUNCH(__bf16, 1); else H16S_LAUNCH(__bf16, 0); }
+    SRK_CHECK_LAUNCH();
+    return SRK_OK;
+  }
   const int tilesW = srk_div_up(a.OW, HW_TW), tilesH = srk_div_up(a.OH, 4 * mt);
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)(srk_round_up(a.Cout, 64) / 64));
-  const bool un = a.in_mode == SRK_IN_UNSHUFFLE;
   if (a.wp_format == 7) {
     if (mt == 4) { if (un) H16_LAUNCH(_Float16, 1, 4); else H16_LAUNCH(_Float16, 0, 4); }
     else { if (un) H16_LAUNCH(_Float16, 1, 2); else H16_LAUNCH(_Float16, 0, 2); }
@@ -540,6 +739,7 @@ int launch_h16_any(const srk_conv_args& a, int mt, hipStream_t st) {
   return SRK_OK;
 }
 #undef H16_LAUNCH
+#undef H16S_LAUNCH
 
 }  // namespace
 
@@ -549,15 +749,17 @@ extern "C" int srk_debug_set_h16_stamps(void* p) {
 }
 #endif
 
-extern "C" int srk_debug_set_h16_mt(int mt) { g_h16_mt = (mt == 2 || mt == 4) ? mt : 0; return SRK_OK; }
+extern "C" int srk_debug_set_h16_mt(int mt) { g_h16_mt = (mt == 1 || mt == 2 || mt == 4) ? mt : 0; return SRK_OK; }
 
-// Rows per wave: 16-row tiles (MT = 4: fewer halo rows, weight reads and barriers per MFMA; one workgroup per CU either way) when
-// they fill the chip (>= 200 workgroups), else 8-row tiles.  SRK_H16_MT = 2 | 4 / srk_debug_set_h16_mt force one (A/B, tests).
+// Form of the kernel: 16-row tiles (MT = 4: fewer halo rows, weight reads and barriers per MFMA; one workgroup per CU) when they
+// fill the chip (>= 200 workgroups), else the shared-CU form (8-row tiles, two workgroups per CU; at the c4 trunk it runs a
+// dense block in 165 us against 157-170 of MT = 4 and 198 of the one-workgroup-per-CU 8-row form MT = 2, which stays selectable).
+// SRK_H16_MT = 1 | 2 | 4 / srk_debug_set_h16_mt force one (A/B, tests).
 int srk_conv_h16_mt(const srk_conv_args& a) {
   if (g_h16_mt < 0) { const char* e = getenv("SRK_H16_MT"); g_h16_mt = e ? atoi(e) : 0; }
-  if (g_h16_mt == 2 || g_h16_mt == 4) return g_h16_mt;
+  if (g_h16_mt == 1 || g_h16_mt == 2 || g_h16_mt == 4) return g_h16_mt;
   const long wg16 = (long)a.N * srk_div_up(a.OH, 16) * srk_div_up(a.OW, HW_TW) * (srk_round_up(a.Cout, 64) / 64);
-  return wg16 >= 200 ? 4 : 2;
+  return wg16 >= 200 ? 4 : 1;
 }
 
 int srk_conv_h16_check(const srk_conv_args& a) {
@@ -601,8 +803,11 @@ int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st) {
 }
 
 int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len) {
-  snprintf(buf, len, "conv3x3_h16_kernel<%s, %d, %d, %s>", a.wp_format == 7 ? "_Float16" : "__bf16", a.in_mode, srk_conv_h16_mt(a),
-           (a.flags & SRK_CONV_OUT_F32) ? "true" : "false");
+  if (srk_conv_h16_mt(a) == 1)
+    snprintf(buf, len, "conv3x3_h16s_kernel<%s, %d, %s>", a.wp_format == 7 ? "_Float16" : "__bf16", a.in_mode, (a.flags & SRK_CONV_OUT_F32) ? "true" : "false");
+  else
+    snprintf(buf, len, "conv3x3_h16_kernel<%s, %d, %d, %s>", a.wp_format == 7 ? "_Float16" : "__bf16", a.in_mode, srk_conv_h16_mt(a),
+             (a.flags & SRK_CONV_OUT_F32) ? "true" : "false");
   return SRK_OK;
 }
 

@@ -69,7 +69,7 @@ class L_PW:
 
 
 @pytest.mark.parametrize("fmt", [7, 8])
-@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("mt", [1, 2, 4])          # 1 = the shared-CU form (conv3x3_h16s_kernel), 2 / 4 = 8- / 16-row tiles
 @pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 32, 32, 2), (320, 64, 16, 32, 1), (32, 64, 9, 7, 2), (64, 128, 33, 17, 1),
                                          (128, 64, 20, 40, 1), (32, 64, 5, 3, 1), (64, 64, 1, 1, 1), (96, 192, 16, 35, 2)])
 def test_h16_conv_fwd(U, fmt, mt, ci, co, h, w, n):
@@ -86,7 +86,7 @@ def test_h16_conv_fwd(U, fmt, mt, ci, co, h, w, n):
 
 
 @pytest.mark.parametrize("fmt", [7, 8])
-@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("mt", [1, 2, 4])
 def test_h16_slices_residuals_mask_and_dgrad(U, fmt, mt):
     """the dense-block addressing (channel prefix in, channel slice out, two residuals, alpha, LeakyReLU' mask) and the data
     gradient (transposed, tap-flipped weights) on the 16-bit kernels"""
@@ -129,7 +129,7 @@ def test_h16_slices_residuals_mask_and_dgrad(U, fmt, mt):
 
 
 @pytest.mark.parametrize("fmt", [7, 8])
-@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("mt", [1, 2, 4])
 def test_h16_pixel_shuffle_fold_and_unshuffle(U, fmt, mt):
     L = U.L
     L.lib().srk_debug_set_h16_mt(mt)
@@ -350,3 +350,32 @@ def test_h16_warmup_step_with_loss_scaling_matches_oracle_update(srk):
         upd = new[k].cpu() - gsd[k]
         # Adam's first steps are ~lr * sign(g): compare where the oracle's gradient is not tiny
         assert ((upd - upd_ref).abs().mean() / upd_ref.abs().mean()).item() < 0.1, k
+
+
+def test_h16_gan_iteration_with_fp16_generator(srk):
+    """The full G+D iteration (esrgan.py:457-626) with the GENERATOR in fp16 activation storage (the discriminators stay fp32): the
+    G-phase loss and generator gradients against the exact-fp32 path on the same weights and batch, then whole iterations with the
+    loss scaler in place (finite losses, weights move, scale stays at 2^16)."""
+    import importlib
+    train = importlib.import_module("super-resolution_amd.train")
+    lr, hr = O.jet_images(4, 1, 64, 64, 31, 2)
+    res = {}
+    for mode in ("f32", "fp16"):
+        torch.manual_seed(0)
+        st = train.Stepper(workload="gan", res_blocks=1, filters=64, device=torch.device("cuda"), hr=64, factor=2, res_scale=0.2)
+        st.generator._engine.precision = mode
+        loss_G, generated, gt, parts = st.g_phase_loss(lr.cuda(), hr.cuda())
+        (loss_G * (1024.0 if mode == "fp16" else 1.0)).backward()
+        named = dict(st.generator.named_parameters())
+        res[mode] = (loss_G.item(), {k: named[k].grad.detach().cpu() / (1024.0 if mode == "fp16" else 1.0)
+                                     for k in ("conv1.weight", "res_blocks.0.dense_blocks.1.b3.0.weight", "upsampling.0.weight", "conv3.2.weight")})
+    assert abs(res["fp16"][0] - res["f32"][0]) < 2e-3 * abs(res["f32"][0])
+    for k, g in res["f32"][1].items():
+        assert _mrel(res["fp16"][1][k], g) < 2e-2, k
+    st.generator.zero_grad(set_to_none=True)
+    w0 = st.generator.conv2.weight.detach().clone()
+    for _ in range(3):
+        out = st.step(lr.cuda(), hr.cuda())
+        assert torch.isfinite(out["g_loss"]).all() and all(torch.isfinite(v).all() for v in out["d_loss"].values())
+    assert st._grad_scaler is not None and st._grad_scaler.get_scale() == 65536.0
+    assert not torch.equal(st.generator.conv2.weight.detach(), w0)
