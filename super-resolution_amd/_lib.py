@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -92,6 +92,8 @@ def lib():
         L.srk_pack_weights_h16.argtypes = [_fp, C.c_int, C.c_int64, C.c_int, _fp]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_conv3x3_seq.argtypes = [C.POINTER(ConvArgs), C.c_int, _fp]
+        L.srk_conv3x3_seq_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_int, C.c_char_p, C.c_size_t]
+        L.srk_debug_set_h16_chain.argtypes = [C.c_int]
         L.srk_debug_set_conv_small.argtypes = [C.c_int]
         L.srk_debug_set_wino42_nmt.argtypes = [C.c_int]
         L.srk_conv3x3_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_char_p, C.c_size_t]
@@ -253,16 +255,28 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):
 
 def conv3x3_seq(calls):
     """``calls``: list of (x, wp, bias, y, kwargs) as for conv3x3 -- launched back to back on the current stream by ONE C call
-    (srk_conv3x3_seq: a dense block's five forward or five data-gradient convolutions).  While bench.py brackets launches with
-    events they go one by one, so that every launch keeps its own time."""
-    if KernelTimer.active:
-        for x, wp, bias, y, kw in calls:
-            conv3x3(x, wp, bias, y, **kw)
-        return
+    (srk_conv3x3_seq: a dense block's five forward or five data-gradient convolutions; with 16-bit storage they may go out as ONE
+    persistent kernel, the chain form).  While bench.py brackets launches with events, a sequence that is not one kernel goes conv by
+    conv, so that every launch keeps its own time."""
     n = len(calls)
     arr = (ConvArgs * n)()
     for a, (x, wp, bias, y, kw) in zip(arr, calls):
         _fill_conv_args(a, x, wp, bias, y, **kw)
+    if KernelTimer.active:
+        buf = C.create_string_buffer(96)
+        check(lib().srk_conv3x3_seq_kernel_name(arr, n, buf, 96), "srk_conv3x3_seq_kernel_name")
+        name = buf.value.decode()
+        if not name:
+            for x, wp, bias, y, kw in calls:
+                conv3x3(x, wp, bias, y, **kw)
+            return
+        if KernelTimer.detail:
+            name += f" n={n} Cin={arr[0].Cin}..{arr[n - 1].Cin} {'m' if arr[0].mask else 'b'}"
+        e0, e1 = KernelTimer.bracket(name, sum(2.0 * a.N * a.OH * a.OW * a.Cout * a.Cin * 9 for a in arr))
+        e0.record()
+        check(lib().srk_conv3x3_seq(arr, n, stream_ptr()), "srk_conv3x3_seq")
+        e1.record()
+        return
     check(lib().srk_conv3x3_seq(arr, n, stream_ptr()), "srk_conv3x3_seq")
 
 

@@ -1087,6 +1087,9 @@ int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st);      // srk_
 int srk_conv_wino42_nmt(const srk_conv_args& a);
 int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st);         // srk_conv_h16.hip (wp_format 7 / 8)
 int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len);
+int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st);   // 1: launched as one chain kernel, 0: not eligible, < 0: error
+int srk_conv_h16_chain_would(const srk_conv_args* args, int n);
+int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1169,10 +1172,25 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
 
 extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
   if (!args || n <= 0) return SRK_ERR_BAD_ARG;
+  {
+    // 16-bit storage: a dense block's sequence as ONE persistent launch (srk_conv_h16.hip, "the chain form")
+    const int rc = srk_launch_conv_h16_chain(args, n, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    if (rc == 1) return SRK_OK;
+  }
   for (int i = 0; i < n; ++i) {
     const int rc = srk_conv3x3(args + i, stream);
     if (rc) return rc;
   }
+  return SRK_OK;
+}
+
+// Name of the ONE kernel srk_conv3x3_seq would launch for the whole sequence (the chain form), or "" when it launches the convolutions
+// one by one (then srk_conv3x3_kernel_name names each).
+extern "C" int srk_conv3x3_seq_kernel_name(const srk_conv_args* args, int n, char* buf, size_t len) {
+  if (!args || n <= 0 || !buf || len < 8) return SRK_ERR_BAD_ARG;
+  buf[0] = 0;
+  if (srk_conv_h16_chain_would(args, n) == 1) return srk_conv_h16_chain_name(args, n, buf, len);
   return SRK_OK;
 }
 

@@ -21,6 +21,7 @@
 #include "srk_epilogue.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -35,9 +36,12 @@ namespace {
 __device__ unsigned long long* g_h16_stamps = nullptr;
 #define H16_STAMP(k) do { if (threadIdx.x == 0 && g_h16_stamps) { g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define H16_STAMP_L(k) do { if (threadIdx.x == 256 && g_h16_stamps) { g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); g_h16_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+// chain form: 8 stamps per conv (0: conv start, 1: main loop done, 2: epilogue issued; loader wave 4: 4 / 5 around the flag wait), 64 per workgroup
+#define H16C_STAMP(T0, c, k) do { if (threadIdx.x == (T0) && g_h16_stamps) g_h16_stamps[(long)blockIdx.x * 64 + (c) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define H16_STAMP(k) do { } while (0)
 #define H16_STAMP_L(k) do { } while (0)
+#define H16C_STAMP(T0, c, k) do { } while (0)
 #endif
 
 template <typename T> struct H16;
@@ -55,6 +59,12 @@ template <> struct H16<__bf16> {
 // the kernels' host stubs -- undefined __device_stub__ symbols at load time, no diagnostic.)
 __device__ __forceinline__ void h16_dma(__amdgpu_buffer_rsrc_t rs, float4* dst, unsigned vo, unsigned so) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+}
+// the same with device-scope coherence (sc1: the load is served from behind the XCD's own L2, so it sees what a workgroup on ANOTHER
+// XCD has written through during this kernel -- the chain form's newest slice)
+constexpr int H16_AUX_SC1 = 16;
+__device__ __forceinline__ void h16_dma_dev(__amdgpu_buffer_rsrc_t rs, float4* dst, unsigned vo, unsigned so) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, H16_AUX_SC1);
 }
 
 constexpr int HW_TW = 32, HW_IW = HW_TW + 2;       // tile width / halo width
@@ -77,7 +87,8 @@ template <int MT> struct HGeo {
 // ------------------------------------------------------------------------------------------------------------------ epilogue
 // acc[m][t][reg]: output row MT wv + m of the tile, pixel i = (reg & 3) + 8 (reg >> 2) + 4 hl of that row, channel n0 + 32 t + l32.
 // Item (m, j), j = 0..3: pixel pl = 8 j + (lane >> 3), channels n0 + 8 (lane & 7) .. + 7.  NS = how many of r1 / r2 / mask exist.
-template <typename T, int MT, int NS, bool OUTF32>
+// SAUX = cache-policy bits of the stores (0; the chain form writes through to device scope, see below).
+template <typename T, int MT, int NS, bool OUTF32, int SAUX = 0>
 __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][2], float* ls, int n, int oh0, int ow0, int n0, int wv, int lane) {
   typedef typename H16<T>::v8 v8;
   constexpr int TB = OUTF32 ? 1 : (NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1));    // M tiles per batch (loads ahead of stores)
@@ -222,7 +233,7 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
           for (int e = 0; e < 8; ++e) ov[e] = o[e];
           const v8 hv = __builtin_convertvector(ov, v8);
           const unsigned off = ok ? (unsigned)(pix[mm][j] * a.y_ldc + ch) * (unsigned)YB : H_OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
         }
       }
     }
@@ -658,6 +669,283 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
   }
 }
 
+// ------------------------------------------------------------------------------------------ the chain form
+// A DenseResidualBlock is five convolutions over ONE dense buffer: conv k reads channel slices 0..k-1 and writes slice k (forward
+// and data gradient alike).  As five launches, 13 us of each (first stage arriving on every CU at once, 17 MB of stores at the end,
+// the kernel boundary) overlap with nothing: 39 % of the block's time.  This kernel runs the whole sequence in one launch, one
+// workgroup per tile for all of it, as ONE continuous stream of stages (ascending channels: old slices first):
+//   * conv k+1's first stage is loaded while conv k's last stage is computed -- its channels are OLD slices, complete (halo
+//     included) since the tile's neighbours finished conv k-1;
+//   * the only data a conv needs from its predecessor is its LAST 64 channels (two stages).  Before the loader waves fetch them they
+//     wait until the (up to) eight neighbouring tiles have published conv k: flags[tile] = epoch + k + 1, written (release, device
+//     scope) by the last of the tile's four MFMA waves to see its stores acknowledged -- a check the MFMA waves make a third of
+//     the way into the NEXT conv's first stage, where it costs them nothing;
+//   * those two stages are fetched with device-scope loads (sc1), the outputs are stored with sc1 (write-through): tiles on
+//     different XCDs do not share an L2.  Every other load touches data that either predates the launch or was already read this
+//     way by the same XCD... see DESIGN 4d for the full argument; H16_CHAIN_ALL_DEV makes every halo load of convs >= 1 sc1.
+// No workgroup ever waits for a tile that is not resident or on its way: the grid is at most one workgroup per CU (host-checked)
+// and the library keeps at most one chain kernel in flight per device.  A wait that still runs into the time limit (2 s) sets
+// *err and goes on -- the kernel always drains; the host turns that into an error on the next call.
+constexpr int H16_CHAIN_MAX = 8;
+struct h16_chain_args {
+  srk_conv_args c[H16_CHAIN_MAX];
+  int n;
+  unsigned epoch;
+  unsigned* flags;
+  unsigned* err;
+};
+#ifndef H16_CHAIN_ALL_DEV
+#define H16_CHAIN_ALL_DEV 0
+#endif
+#ifndef H16_CHAIN_SIG_STEP
+#define H16_CHAIN_SIG_STEP 12
+#endif
+
+template <typename T, bool XL>
+__global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const h16_chain_args A) {
+  constexpr int STORE_AUX = XL ? 0 : H16_AUX_SC1;
+  typedef typename H16<T>::v8 v8;
+  constexpr int MT = 4;
+  typedef HGeo<MT> G;
+  __shared__ float4 smem[2 * G::STAGE4 + 1];
+  unsigned* const wg_cnt = reinterpret_cast<unsigned*>(smem + 2 * G::STAGE4);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  const int gH = A.c[0].H, gW = A.c[0].W;                 // one geometry for the whole chain (host-checked)
+  const int tilesW = (gW + HW_TW - 1) / HW_TW, tilesH = (gH + G::TH - 1) / G::TH;
+  int bid = blockIdx.x;
+  {
+    const int Tn = gridDim.x;
+    if ((Tn & 7) == 0) bid = (bid & 7) * (Tn >> 3) + (bid >> 3);
+  }
+  const int tile = bid;
+  const int tx = bid % tilesW; bid /= tilesW;
+  const int ty = bid % tilesH; bid /= tilesH;
+  const int n = bid;
+  const int oh0 = ty * G::TH, ow0 = tx * HW_TW;
+  const int nconv = A.n;
+  if (tid == 0) *wg_cnt = 0;
+
+  if (wv >= 4) {
+    // ------------------------------------------------------------------------------------------------------ loader waves
+    const int lw = wv - 4;
+    constexpr int NXJ = (G::HPIECES + H16_NLOAD - 1) / H16_NLOAD, NWJ = G::WPIECES / H16_NLOAD;
+    const unsigned wvo = (unsigned)(lane * 16);
+    // the neighbour this lane watches (lanes 0..8; the tile itself and tiles outside the image need no wait)
+    const int ndy = lane / 3 - 1, ndx = lane % 3 - 1;
+    const bool watch = lane < 9 && lane != 4 && (unsigned)(ty + ndy) < (unsigned)tilesH && (unsigned)(tx + ndx) < (unsigned)tilesW;
+    const unsigned* fp = A.flags + (watch ? (n * tilesH + ty + ndy) * tilesW + tx + ndx : tile);
+    auto wait_flags = [&](unsigned target) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+        if (__all((int)(v - target) >= 0)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter
+          if (lane == 0) __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    };
+    unsigned xvo[NXJ];
+    __amdgpu_buffer_rsrc_t xrs, wrs;
+    int CoutP = 64;
+    auto setup = [&](const srk_conv_args& a) {
+      const long img_elems = (long)a.H * a.W * a.x_ldc;
+      const T* ximg = reinterpret_cast<const T*>(a.x) + (long)n * img_elems;
+      CoutP = (a.Cout + 63) & ~63;
+      xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ximg), 0, (unsigned)(img_elems * 2), 0x00020000);
+      wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)((long)(a.Cin >> 5) * 36 * CoutP * 16), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NXJ; ++j) {
+        const int hp = (lw + H16_NLOAD * j) * 16 + (lane >> 2);
+        const int g = (lane & 3) ^ ((hp >> 2) & 3);
+        const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
+        const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+        const unsigned off = (unsigned)(ih * a.W + iw) * (unsigned)a.x_ldc + (unsigned)(a.x_coff + 8 * g);
+        const bool ok = hp < G::NHP && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        xvo[j] = ok ? off * 2u : H_OOB;
+      }
+    };
+    auto stage = [&](int q, int b, bool dev) {           // stage q = input channels 32 q .. 32 q + 31 (ascending here)
+      const unsigned xso = (unsigned)(64 * q);
+      float4* dst = smem + b * G::STAGE4;
+      if (dev) {
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+          const int i = lw + H16_NLOAD * j;
+          if (i < G::HPIECES) h16_dma_dev(xrs, dst + i * 64, xvo[j], xso);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+          const int i = lw + H16_NLOAD * j;
+          if (i < G::HPIECES) h16_dma(xrs, dst + i * 64, xvo[j], xso);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NWJ; ++j) {
+        const int w = lw + H16_NLOAD * j;
+        h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
+      }
+    };
+    setup(A.c[0]);
+    stage(0, 0, false);
+    for (int c = 0; c < nconv; ++c) {
+      const int nq = A.c[c].Cin >> 5;                     // even, >= 4 behind the first conv (host-checked)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // this conv's stage 0 is in LDS; the epilogue scratch (buffer 1) is free
+      for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) {
+          const bool fresh = !XL && c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
+          if (c > 0 && q + 1 == nq - 2) { H16C_STAMP(256, c, 4); wait_flags(A.epoch + (unsigned)c); H16C_STAMP(256, c, 5); }
+          stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && !XL && c > 0));
+          if (c > 0 && q == 0 && lw == 0) {
+            // publish conv c - 1 of this tile: once the four MFMA waves have seen their stores acknowledged (they count themselves in
+            // a third of the way into this stage), write the XCD's dirty lines back and release the flag -- from here, so that the
+            // write-back stalls no MFMA wave
+            while (__hip_atomic_load(wg_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)c) __builtin_amdgcn_s_sleep(2);
+            if (lane == 0) __hip_atomic_store(A.flags + tile, A.epoch + (unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            H16C_STAMP(256, c, 6);
+          }
+        } else if (c + 1 < nconv) {
+          setup(A.c[c + 1]);                              // the next conv's first stage (old slices) beside this conv's last one
+          stage(0, 0, H16_CHAIN_ALL_DEV != 0 && !XL);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------- MFMA waves
+  f32x16 acc[MT][2];
+  constexpr int SPS = MT + 2, STEPS1 = 3 * SPS, STEPS = 2 * STEPS1;
+  int aaddr[STEPS1];
+  int baddr = 0;
+  // (the fragment addresses are formed again for every conv, from a lane id the compiler cannot see through: kept live across the
+  // epilogue they are what it spills, and it reloads them from scratch in the middle of the main loop)
+  auto frag_addresses = [&]() {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int hlo = lo >> 5, l32o = lo & 31;
+#pragma unroll
+    for (int i = 0; i < STEPS1; ++i) {
+      const int s = i / SPS, ri = i % SPS;
+      const int hp = (MT * wv + ri) * HW_IW + l32o + s;
+      aaddr[i] = hp * 64 + ((hlo ^ ((hp >> 2) & 1)) + 2 * ((hp >> 3) & 1)) * 16;
+    }
+    baddr = (G::WBASE + hlo * 64 + l32o) * 16;
+  };
+  constexpr int DEFER = 4, AHEAD = 4;
+  constexpr int RINGP = STEPS & 7;
+  v8 Af[8], Bf[2][3][2];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  const char* sm = reinterpret_cast<const char*>(smem);
+  bool sig_pending = false;
+  // (buffer 1 lies beyond the 64 KB a ds_read offset field reaches: its byte offset is added per read from an SGPR the compiler cannot
+  // see through -- left to itself it hoists all 36 sums out of the stage loop and spills them)
+  int pofs = 0;
+  auto rdA = [&](int P, int L) {
+    const int i = L % STEPS1, kk = L / STEPS1;
+    return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + (P ? pofs : 0) + (kk ? (aaddr[i] ^ 32) : aaddr[i])));
+  };
+  auto rdB = [&](int P, int S, int r, int t) {
+    const int kk = S / 3, s = S % 3;
+    return __builtin_bit_cast(v8, *reinterpret_cast<const float4*>(sm + (P ? pofs : 0) + baddr + ((kk * 18 + (3 * r + s) * 2) * 64 + 32 * t) * 16));
+  };
+  auto mfma_step = [&](auto pc, auto lc) {
+    constexpr int P = decltype(pc)::value, L = decltype(lc)::value;
+    constexpr int S = L / SPS, ri = L % SPS;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int m = ri - r;
+      if (m >= 0 && m < MT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = H16<T>::mfma(Af[(RINGP * P + L) & 7], Bf[S & 1][r][t], acc[m][t]);
+      }
+    }
+  };
+  auto head = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) Bf[0][r][t] = rdB(P, 0, r, t);
+#pragma unroll
+    for (int L = 0; L < AHEAD; ++L) Af[(RINGP * P + L) & 7] = rdA(P, L);
+  };
+  // the previous conv of this tile: my stores are acknowledged (the MFMA waves issue no other vector-memory instruction); loader wave 0
+  // counts the four waves and releases the flag
+  auto publish = [&]() {
+    if (sig_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(wg_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sig_pending = false;
+    }
+  };
+  auto stage_fn = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    using Pc = std::integral_constant<int, P>; using Pn = std::integral_constant<int, P ^ 1>;
+    pofs = G::STAGE4 * 16;
+    asm volatile("" : "+s"(pofs));
+    auto step = [&](auto lc) {
+      constexpr int L = decltype(lc)::value;
+      constexpr int S = L / SPS, ri = L % SPS;
+      if constexpr (P == 0 && L == H16_CHAIN_SIG_STEP) publish();
+      if constexpr (L + AHEAD < STEPS) Af[(RINGP * P + L + AHEAD) & 7] = rdA(P, L + AHEAD);
+      if constexpr (ri >= 1 && ri <= 3 && S < 5) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) Bf[(S + 1) & 1][ri - 1][t] = rdB(P, S + 1, ri - 1, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(Pc{}, lc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, STEPS - DEFER>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    head(Pn{});
+    __builtin_amdgcn_sched_barrier(0);
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (mfma_step(Pc{}, std::integral_constant<int, STEPS - DEFER + Ls>{}), ...); }(std::make_integer_sequence<int, DEFER>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  float* ls = reinterpret_cast<float*>(smem + G::STAGE4) + wv * 2048;      // transposition scratch: buffer 1, which held the LAST stage
+  for (int c = 0; c < nconv; ++c) {
+    const srk_conv_args& a = A.c[c];
+    const int nq = a.Cin >> 5;
+    frag_addresses();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (c > 0) my reads of the epilogue scratch
+    __builtin_amdgcn_s_barrier();
+    H16C_STAMP(0, c, 0);
+    head(I0{});
+    for (int q = 0; q < nq; q += 2) {
+      stage_fn(I0{});
+      stage_fn(I1{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    H16C_STAMP(0, c, 1);
+    const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else h16_epilogue<T, MT, 3, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    H16C_STAMP(0, c, 2);
+    sig_pending = c + 1 < nconv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight packing (formats 7 / 8)
 // dst[q16][tap][h][Mp64][8] of T, k = 16 q + 8 h + e.  Work item = one (q, tap, h, m): 8 consecutive k, one 16-byte store.
 template <typename T>
@@ -792,6 +1080,155 @@ int srk_conv_h16_check(const srk_conv_args& a) {
     if (a.mask && a.m_ldc > ld) ld = a.m_ldc;
     if (px * ld * 2 > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
   }
+  return SRK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ the chain form: host side
+namespace {
+int g_h16_chain_xl = -1;       // 1 (default): the same-XCD variant where whole images fall to one XCD; 0: always the device-scope variant
+int g_h16_chain = -1;          // 0: never, 1: where the 16-row form would run (default), 2: wherever the sequence is eligible (tests)
+struct ChainDev {
+  unsigned* flags = nullptr;   // one word per tile (device)
+  unsigned* err = nullptr;     // pinned host word the kernel writes when a flag wait timed out
+  unsigned epoch = 0;
+  int cus = 0;
+  hipEvent_t ev = nullptr;     // end of the newest chain launch, once a second stream has shown up
+  hipStream_t last = nullptr;
+  bool used = false, multi = false, dead = false;
+};
+ChainDev g_chain_dev[16];
+std::mutex g_chain_mu;
+constexpr int H16_CHAIN_FLAGS = 1024;
+
+// do the channel ranges [ca, ca + na) of view (pa, lda) and [cb, cb + nb) of (pb, ldb) share memory?  (px pixels per tensor, 16-bit elements)
+bool h16_views_overlap(const void* pa, int lda, int ca, int na, const void* pb, int ldb, int cb, int nb, long px) {
+  if (na <= 0 || nb <= 0) return false;
+  if (pa == pb && lda == ldb) return ca < cb + nb && cb < ca + na;
+  const uintptr_t a0 = (uintptr_t)pa + 2u * (uintptr_t)ca, a1 = (uintptr_t)pa + 2u * ((uintptr_t)(px - 1) * lda + ca + na);
+  const uintptr_t b0 = (uintptr_t)pb + 2u * (uintptr_t)cb, b1 = (uintptr_t)pb + 2u * ((uintptr_t)(px - 1) * ldb + cb + nb);
+  return a0 < b1 && b0 < a1;
+}
+
+// Is args[0..n) a sequence the chain kernel runs?  (The dense-block pattern: every conv takes at most its LAST 64 input channels from its
+// predecessor's output, nothing from its own.)
+bool h16_chain_eligible(const srk_conv_args* args, int n, int mode, int cus) {
+  if (mode <= 0 || n < 2 || n > H16_CHAIN_MAX) return false;
+  const srk_conv_args& f = args[0];
+  if (f.wp_format != 7 && f.wp_format != 8) return false;
+  if (mode == 1 && srk_conv_h16_mt(f) != 4) return false;
+  const long tiles = (long)f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW);
+  if (tiles > cus || tiles > H16_CHAIN_FLAGS) return false;
+  const long px = (long)f.N * f.H * f.W;
+  for (int c = 0; c < n; ++c) {
+    const srk_conv_args& a = args[c];
+    if (srk_conv_h16_check(a) != SRK_OK) return false;
+    if (a.wp_format != f.wp_format || a.in_mode != SRK_IN_PLAIN || a.ps_out || (a.flags & SRK_CONV_OUT_F32)) return false;
+    if (a.N != f.N || a.H != f.H || a.W != f.W || a.Cout > 64 || (a.Cin % 64)) return false;
+    if (c > 0 && a.Cin < 128) return false;
+    if (h16_views_overlap(a.y, a.y_ldc, a.y_coff, a.Cout, a.x, a.x_ldc, a.x_coff, a.Cin, px)) return false;
+    if (c > 0) {
+      const srk_conv_args& p = args[c - 1];
+      if (h16_views_overlap(p.y, p.y_ldc, p.y_coff, p.Cout, a.x, a.x_ldc, a.x_coff, a.Cin - 64, px)) return false;
+    }
+  }
+  return true;
+}
+
+int h16_chain_mode() {
+  if (g_h16_chain < 0) { const char* e = getenv("SRK_H16_CHAIN"); g_h16_chain = e ? atoi(e) : 1; }
+  return g_h16_chain;
+}
+
+ChainDev* h16_chain_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  ChainDev& D = g_chain_dev[dev];
+  if (!D.flags && !D.dead) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { D.dead = true; return nullptr; }
+    D.cus = pr.multiProcessorCount;
+    if (hipMalloc((void**)&D.flags, H16_CHAIN_FLAGS * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(D.flags, 0, H16_CHAIN_FLAGS * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void**)&D.err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      D.dead = true; D.flags = nullptr;
+      return nullptr;
+    }
+    *D.err = 0;
+  }
+  return D.dead ? nullptr : &D;
+}
+}  // namespace
+
+extern "C" int srk_debug_set_h16_chain(int mode) {          // + 16: the same-XCD variant where the geometry allows it
+  g_h16_chain_xl = (mode & 16) ? 1 : 0;
+  mode &= 15;
+  g_h16_chain = (mode >= 0 && mode <= 2) ? mode : 1;
+  return SRK_OK;
+}
+
+// 1: the sequence goes out as ONE chain launch; 0: not eligible (the caller launches the convs one by one); < 0: error
+int srk_conv_h16_chain_would(const srk_conv_args* args, int n) {
+  const int mode = h16_chain_mode();
+  if (mode <= 0 || n < 2 || (args[0].wp_format != 7 && args[0].wp_format != 8)) return 0;
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  ChainDev* D = h16_chain_dev();
+  if (!D) return 0;
+  return h16_chain_eligible(args, n, mode, D->cus) ? 1 : 0;
+}
+
+int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) {
+  const int mode = h16_chain_mode();
+  if (mode <= 0 || n < 2 || (args[0].wp_format != 7 && args[0].wp_format != 8)) return 0;
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  ChainDev* D = h16_chain_dev();
+  if (!D) return 0;
+  if (*reinterpret_cast<volatile unsigned*>(D->err)) {
+    // a flag wait of an earlier chain launch ran into its time limit: that launch's results are not to be trusted
+    fprintf(stderr, "libsrk: a conv3x3 chain launch timed out waiting for a neighbouring tile (results of that launch are invalid); "
+                    "the chain form is now off for this device (SRK_H16_CHAIN=0 avoids it from the start)\n");
+    *D->err = 0;
+    D->dead = true;
+    return SRK_ERR_LAUNCH;
+  }
+  if (!h16_chain_eligible(args, n, mode, D->cus)) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }   // (the epoch would be baked into the graph)
+  // at most ONE chain kernel in flight per device: two of them, each holding part of the CUs and waiting for tiles that cannot become
+  // resident, would wait for each other.  One stream orders its launches by itself; from the first launch on a second stream on, every
+  // chain launch is followed by an event the next one (on whatever stream) waits for.
+  if (D->used && D->last != st) {
+    if (!D->ev && hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) != hipSuccess) return SRK_ERR_LAUNCH;
+    if (!D->multi) { if (hipEventRecord(D->ev, D->last) != hipSuccess) return SRK_ERR_LAUNCH; D->multi = true; }
+    if (hipStreamWaitEvent(st, D->ev, 0) != hipSuccess) return SRK_ERR_LAUNCH;
+  }
+  h16_chain_args A;
+  for (int c = 0; c < n; ++c) A.c[c] = args[c];
+  A.n = n; A.epoch = D->epoch; A.flags = D->flags; A.err = D->err;
+  D->epoch += (unsigned)n;
+  const srk_conv_args& f = args[0];
+  const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
+  // whole images per XCD (workgroup i runs on XCD i % 8, and the kernel hands XCD x the tiles [x T/8, (x + 1) T/8)): every neighbour of a
+  // tile then shares its L2, and nothing has to be written through or fetched around it
+  const int per_img = srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW);
+  if (g_h16_chain_xl < 0) { const char* e = getenv("SRK_H16_CHAIN_XL"); g_h16_chain_xl = e ? atoi(e) : 0; }
+  const bool xl = g_h16_chain_xl == 1 && (grid.x % 8) == 0 && ((grid.x / 8) % per_img) == 0;
+  if (f.wp_format == 7) {
+    if (xl) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, true>), grid, dim3(H16_THREADS), 0, st, A);
+    else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, false>), grid, dim3(H16_THREADS), 0, st, A);
+  } else {
+    if (xl) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, true>), grid, dim3(H16_THREADS), 0, st, A);
+    else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, false>), grid, dim3(H16_THREADS), 0, st, A);
+  }
+  SRK_CHECK_LAUNCH();
+  D->used = true; D->last = st;
+  if (D->multi && hipEventRecord(D->ev, st) != hipSuccess) return SRK_ERR_LAUNCH;
+  return 1;
+}
+
+int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len) {
+  (void)n;
+  snprintf(buf, len, "conv3x3_h16_chain_kernel<%s>", args[0].wp_format == 7 ? "_Float16" : "__bf16");
   return SRK_OK;
 }
 

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Chain form of the 16-bit conv (one persistent launch per dense block) against the same sequence launched conv by conv:
+results (max |diff| in units of the output scale) on several geometries, repeated to catch ordering races, then timing at
+BASELINE configs[4]'s trunk geometry.  FMT=7|8, REPS."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+L = importlib.import_module("super-resolution_amd")._lib
+fmt = int(os.environ.get("FMT", 7))
+dt = {7: torch.float16, 8: torch.bfloat16}[fmt]
+F = 64
+
+
+class PW:
+    def __init__(self, t, fmt):
+        self.t, self.fmt = t, fmt
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def make_block(N, H, W, seed, backward=False):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    D = torch.zeros(N, H, W, 5 * F, device="cuda", dtype=dt)
+    D[..., :F] = torch.randn(N, H, W, F, device="cuda", generator=g).to(dt)
+    out = torch.zeros(N, H, W, 5 * F, device="cuda", dtype=dt)
+    M = torch.randn(N, H, W, 5 * F, device="cuda", generator=g).to(dt)     # mask source (forward activations) for the backward pattern
+    ws = []
+    for k in range(1, 6):
+        ci = k * F
+        w = torch.randn(F, ci, 3, 3, device="cuda", generator=g) * (1.0 / (3.0 * ci ** 0.5))
+        b = torch.randn(F, device="cuda", generator=g) * 0.1
+        wp = torch.empty(L.packed_floats(ci, F, fmt), device="cuda")
+        t = L.PackTable(D.device, fmt); t.add(w, wp, M=F, k_off=0, k_len=ci, K_total=ci); t.run()
+        ws.append((PW(wp, fmt), b))
+    geo = dict(N=N, H=H, W=W, OH=H, OW=W, Cout=F)
+    calls = []
+    for k in range(1, 5):
+        if backward:
+            calls.append((L.View(D, 0, k * F), ws[k - 1][0], None, L.View(D, k * F, F), dict(Cin=k * F, mask=L.View(M, k * F, F), mask_slope=0.2, **geo)))
+        else:
+            calls.append((L.View(D, 0, k * F), ws[k - 1][0], ws[k - 1][1], L.View(D, k * F, F), dict(Cin=k * F, slope=0.2, **geo)))
+    calls.append((L.View(D, 0, 5 * F), ws[4][0], None if backward else ws[4][1], L.View(out, 0, F),
+                  dict(Cin=5 * F, alpha=0.2, r1=L.View(D, 0, F), beta1=1.0, r2=L.View(M, 0, F), beta2=0.5, **geo)))
+    return D, out, calls, (ws, M)
+
+
+def run(calls, mode):
+    L.lib().srk_debug_set_h16_chain(mode)
+    L.conv3x3_seq(calls)
+
+
+def check(N, H, W, reps, backward):
+    D, out, calls, keep = make_block(N, H, W, 1 + N + H, backward)
+    run(calls, 0)
+    torch.cuda.synchronize()
+    refD, refO = D.clone(), out.clone()
+    worst = 0.0
+    for r in range(reps):
+        D[..., F:] = 0; out.zero_()
+        run(calls, 2 if r % 2 == 0 else 18)
+        torch.cuda.synchronize()
+        d = max((D.float() - refD.float()).abs().max().item(), (out.float() - refO.float()).abs().max().item())
+        worst = max(worst, d)
+    scale = refD.float().abs().max().item()
+    name = L.lib().srk_conv3x3_seq_kernel_name
+    print(f"{'bwd' if backward else 'fwd'} N={N} {H}x{W}: max |chain - separate| = {worst:.3e} (scale {scale:.2f}) over {reps} runs", flush=True)
+    return worst / scale
+
+
+def timing(N, H, W, backward):
+    blocks = [make_block(N, H, W, 100 + i, backward) for i in range(6)]
+    res = {}
+    for mode in (0, 1, 17):
+        for i in range(6): run(blocks[i % 6][2], mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(60): run(blocks[i % 6][2], mode)
+        e1.record(); torch.cuda.synchronize()
+        res[mode] = e0.elapsed_time(e1) / 60 * 1e3
+    fl = sum(2.0 * N * H * W * F * k * F * 9 for k in range(1, 6))
+    print(f"{'bwd' if backward else 'fwd'} block at N={N} {H}x{W}: separate {res[0]:.1f} us = {fl / res[0] / 1e6:.0f} TF/s, chain {res[1]:.1f} us = {fl / res[1] / 1e6:.0f} TF/s, "
+          f"chain (device-scope variant) {res[17]:.1f} us = {fl / res[17] / 1e6:.0f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    reps = int(os.environ.get("REPS", 5))
+    bad = 0
+    for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (8, 128, 128)):
+        for bw in (False, True):
+            r = check(N, H, W, reps if N < 8 else 3 * reps, bw)
+            bad += r > 4e-3
+    print("MISMATCH" if bad else "results agree", flush=True)
+    if not bad and not os.environ.get("NO_TIMING"):
+        timing(8, 128, 128, False)
+        timing(8, 128, 128, True)
+    sys.exit(1 if bad else 0)
