@@ -674,18 +674,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
 // and data gradient alike).  As five launches, 13 us of each (first stage arriving on every CU at once, 17 MB of stores at the end,
 // the kernel boundary) overlap with nothing: 39 % of the block's time.  This kernel runs the whole sequence in one launch, one
 // workgroup per tile for all of it, as ONE continuous stream of stages (ascending channels: old slices first):
-//   * conv k+1's first stage is loaded while conv k's last stage is computed -- its channels are OLD slices, complete (halo
-//     included) since the tile's neighbours finished conv k-1;
+//   * conv k+1's first stage is loaded while conv k's last stage is computed and its epilogue runs -- its channels are OLD slices,
+//     complete (halo included) since the tile's neighbours finished conv k-1;
 //   * the only data a conv needs from its predecessor is its LAST 64 channels (two stages).  Before the loader waves fetch them they
-//     wait until the (up to) eight neighbouring tiles have published conv k: flags[tile] = epoch + k + 1, written (release, device
-//     scope) by the last of the tile's four MFMA waves to see its stores acknowledged -- a check the MFMA waves make a third of
-//     the way into the NEXT conv's first stage, where it costs them nothing;
-//   * those two stages are fetched with device-scope loads (sc1), the outputs are stored with sc1 (write-through): tiles on
-//     different XCDs do not share an L2.  Every other load touches data that either predates the launch or was already read this
-//     way by the same XCD... see DESIGN 4d for the full argument; H16_CHAIN_ALL_DEV makes every halo load of convs >= 1 sc1.
+//     wait until the (up to) eight neighbouring tiles have published that conv: flags[tile] = epoch + k + 1.  The four MFMA waves
+//     count themselves in (LDS) once their stores are acknowledged -- a third of the way into the NEXT conv's first stage, where the
+//     wait costs them nothing --, loader wave 0 then stores the flag (device scope);
+//   * the outputs are stored write-through (sc1) and those two stages are fetched with device-scope loads (sc1): tiles on different
+//     XCDs do not share an L2.  s_waitcnt vmcnt(0) behind write-through stores = they have reached memory (what the compiler's own
+//     release sequence relies on); no buffer_wbl2 (measured: every workgroup writing the XCD's L2 back costs 30 us per block).
+//     Every other load touches data that predates the launch, or that this XCD cannot hold a stale copy of (nobody reads a slice
+//     before it is written, and its first reads are the sc1 ones); H16_CHAIN_ALL_DEV makes every halo load of convs >= 1 sc1.
 // No workgroup ever waits for a tile that is not resident or on its way: the grid is at most one workgroup per CU (host-checked)
 // and the library keeps at most one chain kernel in flight per device.  A wait that still runs into the time limit (2 s) sets
 // *err and goes on -- the kernel always drains; the host turns that into an error on the next call.
+// Tried and dropped (tools/debug/chain_check.py, 8 x 128 x 128, forward / data-gradient block; five launches: 158 / 168 us; this
+// form: 138 / 143): plain stores + buffer_wbl2 before the flag (171 / 164); plain stores and loads where whole images fall to one
+// XCD (147 / 148, and correctness would hang on the workgroup -> XCD map); the MFMA waves only DUMPING the tile (16-bit, into the
+// free stage buffer) and four loader waves doing residuals / mask / stores beside the next conv's first stage (133 / 148: the
+// next stage's DMA then has to wait for the dump to be read out, which costs what the shorter epilogue saves).
 constexpr int H16_CHAIN_MAX = 8;
 struct h16_chain_args {
   srk_conv_args c[H16_CHAIN_MAX];
@@ -701,9 +708,9 @@ struct h16_chain_args {
 #define H16_CHAIN_SIG_STEP 12
 #endif
 
-template <typename T, bool XL>
+template <typename T>
 __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const h16_chain_args A) {
-  constexpr int STORE_AUX = XL ? 0 : H16_AUX_SC1;
+  constexpr int STORE_AUX = H16_AUX_SC1;
   typedef typename H16<T>::v8 v8;
   constexpr int MT = 4;
   typedef HGeo<MT> G;
@@ -799,9 +806,9 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
       __builtin_amdgcn_s_barrier();                       // this conv's stage 0 is in LDS; the epilogue scratch (buffer 1) is free
       for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) {
-          const bool fresh = !XL && c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
+          const bool fresh = c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
           if (c > 0 && q + 1 == nq - 2) { H16C_STAMP(256, c, 4); wait_flags(A.epoch + (unsigned)c); H16C_STAMP(256, c, 5); }
-          stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && !XL && c > 0));
+          stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && c > 0));
           if (c > 0 && q == 0 && lw == 0) {
             // publish conv c - 1 of this tile: once the four MFMA waves have seen their stores acknowledged (they count themselves in
             // a third of the way into this stage), write the XCD's dirty lines back and release the flag -- from here, so that the
@@ -812,7 +819,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
           }
         } else if (c + 1 < nconv) {
           setup(A.c[c + 1]);                              // the next conv's first stage (old slices) beside this conv's last one
-          stage(0, 0, H16_CHAIN_ALL_DEV != 0 && !XL);
+          stage(0, 0, H16_CHAIN_ALL_DEV != 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1085,7 +1092,6 @@ int srk_conv_h16_check(const srk_conv_args& a) {
 
 // ------------------------------------------------------------------------------------------ the chain form: host side
 namespace {
-int g_h16_chain_xl = -1;       // 1 (default): the same-XCD variant where whole images fall to one XCD; 0: always the device-scope variant
 int g_h16_chain = -1;          // 0: never, 1: where the 16-row form would run (default), 2: wherever the sequence is eligible (tests)
 struct ChainDev {
   unsigned* flags = nullptr;   // one word per tile (device)
@@ -1160,12 +1166,7 @@ ChainDev* h16_chain_dev() {
 }
 }  // namespace
 
-extern "C" int srk_debug_set_h16_chain(int mode) {          // + 16: the same-XCD variant where the geometry allows it
-  g_h16_chain_xl = (mode & 16) ? 1 : 0;
-  mode &= 15;
-  g_h16_chain = (mode >= 0 && mode <= 2) ? mode : 1;
-  return SRK_OK;
-}
+extern "C" int srk_debug_set_h16_chain(int mode) { g_h16_chain = (mode >= 0 && mode <= 2) ? mode : 1; return SRK_OK; }
 
 // 1: the sequence goes out as ONE chain launch; 0: not eligible (the caller launches the convs one by one); < 0: error
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n) {
@@ -1208,18 +1209,8 @@ int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) 
   D->epoch += (unsigned)n;
   const srk_conv_args& f = args[0];
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
-  // whole images per XCD (workgroup i runs on XCD i % 8, and the kernel hands XCD x the tiles [x T/8, (x + 1) T/8)): every neighbour of a
-  // tile then shares its L2, and nothing has to be written through or fetched around it
-  const int per_img = srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW);
-  if (g_h16_chain_xl < 0) { const char* e = getenv("SRK_H16_CHAIN_XL"); g_h16_chain_xl = e ? atoi(e) : 0; }
-  const bool xl = g_h16_chain_xl == 1 && (grid.x % 8) == 0 && ((grid.x / 8) % per_img) == 0;
-  if (f.wp_format == 7) {
-    if (xl) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, true>), grid, dim3(H16_THREADS), 0, st, A);
-    else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, false>), grid, dim3(H16_THREADS), 0, st, A);
-  } else {
-    if (xl) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, true>), grid, dim3(H16_THREADS), 0, st, A);
-    else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, false>), grid, dim3(H16_THREADS), 0, st, A);
-  }
+  if (f.wp_format == 7) hipLaunchKernelGGL(conv3x3_h16_chain_kernel<_Float16>, grid, dim3(H16_THREADS), 0, st, A);
+  else hipLaunchKernelGGL(conv3x3_h16_chain_kernel<__bf16>, grid, dim3(H16_THREADS), 0, st, A);
   SRK_CHECK_LAUNCH();
   D->used = true; D->last = st;
   if (D->multi && hipEventRecord(D->ev, st) != hipSuccess) return SRK_ERR_LAUNCH;

@@ -32,6 +32,7 @@ def U():
 def _reset_form(U):
     yield
     U.L.lib().srk_debug_set_h16_mt(0)
+    U.L.lib().srk_debug_set_h16_chain(1)
 
 
 def _q(t, fmt):
@@ -255,6 +256,127 @@ def test_h16_wgrad_dense_block_batch_unshuffle_and_padded_channels(U, fmt):
 
 
 # ------------------------------------------------------------------------------------------------------------ whole generator
+# ---------------------------------------------------------------------------------------------- the chain form (one launch per dense block)
+def _dense_block_calls(U, fmt, n, h, w, backward, seed):
+    """the engine's two sequences (engine.py _drb_forward / _drb_backward) on random data: conv k reads slices 0..k-1 of D and writes
+    slice k (bias + LeakyReLU, or the LeakyReLU' mask), the fifth writes another buffer with alpha and two residuals"""
+    L, F_ = U.L, 64
+    D = torch.zeros(n, h, w, 5 * F_, device="cuda", dtype=DT[fmt])
+    D[..., :F_] = U.nhwc(_rand((n, F_, h, w), seed)).to(DT[fmt])
+    out = torch.zeros(n, h, w, 2 * F_, device="cuda", dtype=DT[fmt])
+    M = U.nhwc(_rand((n, 5 * F_, h, w), seed + 1)).to(DT[fmt]).contiguous()
+    R2 = U.nhwc(_rand((n, F_, h, w), seed + 2)).to(DT[fmt]).contiguous()
+    keep, calls = [M, R2], []
+    geo = dict(N=n, H=h, W=w, OH=h, OW=w, Cout=F_)
+    for k in range(1, 6):
+        wt = _rand((F_, k * F_, 3, 3), seed + 10 + k, 1.0 / (3.0 * (k * F_) ** 0.5))
+        b = None if backward else _rand((F_,), seed + 20 + k, 0.1).cuda()
+        wp = _pack(U, wt, fmt)
+        keep += [wp, b]
+        if k < 5 and backward:
+            calls.append((L.View(D, 0, k * F_), wp, None, L.View(D, k * F_, F_), dict(Cin=k * F_, mask=L.View(M, k * F_, F_), mask_slope=0.2, **geo)))
+        elif k < 5:
+            calls.append((L.View(D, 0, k * F_), wp, b, L.View(D, k * F_, F_), dict(Cin=k * F_, slope=0.2, **geo)))
+        else:
+            calls.append((L.View(D, 0, 5 * F_), wp, b, L.View(out, F_, F_), dict(Cin=5 * F_, alpha=0.2, r1=L.View(D, 0, F_), beta1=1.0, r2=L.View(R2), beta2=0.5, **geo)))
+    return D, out, calls, keep
+
+
+def _seq_kernel(L, calls):
+    import ctypes as C
+    arr = (L.ConvArgs * len(calls))()
+    for a, (x, wp, bias, y, kw) in zip(arr, calls):
+        L._fill_conv_args(a, x, wp, bias, y, **kw)
+    buf = C.create_string_buffer(96)
+    L.check(L.lib().srk_conv3x3_seq_kernel_name(arr, len(calls), buf, 96), "srk_conv3x3_seq_kernel_name")
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("backward", [False, True])
+@pytest.mark.parametrize("n,h,w", [(1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31)])
+def test_h16_chain_matches_separate_launches(U, fmt, backward, n, h, w):
+    """One persistent launch per dense block (srk_conv3x3_seq, chain form; tiles exchange halos through flags) against the same five
+    convolutions launched one by one (each checked against the fp32 reference above): equal up to the order of the fp32 sums,
+    i.e. one unit in the last place of the 16-bit outputs per conv; and bit-identical from run to run (a race would not be)."""
+    L = U.L
+    D, out, calls, keep = _dense_block_calls(U, fmt, n, h, w, backward, 300 + n + h)
+    L.lib().srk_debug_set_h16_chain(0)
+    assert _seq_kernel(L, calls) == ""
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    refD, refO = D.float().clone(), out.float().clone()
+    assert refD[..., 64:].abs().max().item() > 0.1 and refO[..., 64:].abs().max().item() > 0.1
+    L.lib().srk_debug_set_h16_chain(2)
+    assert _seq_kernel(L, calls).startswith("conv3x3_h16_chain_kernel<")
+    first = None
+    for rep in range(4):
+        D[..., 64:] = 0
+        out.zero_()
+        L.conv3x3_seq(calls)
+        torch.cuda.synchronize()
+        scale = refD.abs().max().item()
+        tol = 6 * TOL16[fmt] * scale          # five convs, each within an ulp of its (differently ordered) fp32 sum
+        assert (D.float() - refD).abs().max().item() <= tol
+        assert (out.float() - refO).abs().max().item() <= tol
+        assert out[..., :64].abs().max().item() == 0
+        if first is None:
+            first = (D.clone(), out.clone())
+        else:
+            assert torch.equal(D, first[0]) and torch.equal(out, first[1])
+
+
+def test_h16_chain_eligibility(U):
+    """what srk_conv3x3_seq sends out as one kernel: only sequences in which a conv takes at most its LAST 64 input channels from its
+    predecessor's output, one geometry, <= 64 outputs, whole 64-channel slices -- everything else goes conv by conv"""
+    L = U.L
+    L.lib().srk_debug_set_h16_chain(2)
+    D, out, calls, keep = _dense_block_calls(U, 7, 1, 16, 32, False, 400)
+    assert _seq_kernel(L, calls).startswith("conv3x3_h16_chain_kernel<_Float16>")
+    assert _seq_kernel(L, calls[:1]) == ""                                     # a single conv
+    assert _seq_kernel(L, calls[1:3]).startswith("conv3x3_h16_chain_kernel")   # any sub-sequence of the pattern
+    # conv 3 reading, as an OLD slice, what conv 2 has just written: not the pattern (swap the order of two convs)
+    assert _seq_kernel(L, [calls[0], calls[2], calls[1]]) == ""
+    # a second conv with 64 inputs would need its predecessor's output as its FIRST stage
+    x, wp, b, y, kw = calls[0]
+    assert _seq_kernel(L, [calls[0], (L.View(D, 64, 64), wp, b, L.View(D, 128, 64), kw)]) == ""
+    # in place
+    assert _seq_kernel(L, [calls[0], (calls[1][0], calls[1][1], calls[1][2], L.View(D, 64, 64), calls[1][4])]) == ""
+    # mixed geometry
+    kw2 = dict(calls[1][4]); kw2.update(H=8, OH=8)
+    assert _seq_kernel(L, [calls[0], (calls[1][0], calls[1][1], calls[1][2], calls[1][3], kw2)]) == ""
+    L.lib().srk_debug_set_h16_chain(1)      # default: only where the 16-row form would run (>= 200 tiles)
+    assert _seq_kernel(L, calls) == ""
+    L.lib().srk_debug_set_h16_chain(0)
+    assert _seq_kernel(L, calls) == ""
+
+
+@pytest.mark.parametrize("backward", [False, True])
+def test_h16_chain_full_size_repeatable(U, backward):
+    """BASELINE configs[4]'s trunk geometry (8 x 128 x 128: 256 tiles, one per CU, on all eight XCDs), default dispatch: the chain result
+    agrees with the separate launches and is bit-identical over 12 runs"""
+    L = U.L
+    D, out, calls, keep = _dense_block_calls(U, 7, 8, 128, 128, backward, 500)
+    L.lib().srk_debug_set_h16_chain(0)
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    refD, refO = D.float().clone(), out.float().clone()
+    L.lib().srk_debug_set_h16_chain(1)
+    assert _seq_kernel(L, calls).startswith("conv3x3_h16_chain_kernel<")
+    first = None
+    for rep in range(12):
+        D[..., 64:] = 0
+        out.zero_()
+        L.conv3x3_seq(calls)
+        torch.cuda.synchronize()
+        tol = 6 * TOL16[7] * refD.abs().max().item()
+        assert (D.float() - refD).abs().max().item() <= tol and (out.float() - refO).abs().max().item() <= tol
+        if first is None:
+            first = (D.clone(), out.clone())
+        else:
+            assert torch.equal(D, first[0]) and torch.equal(out, first[1])
+
+
 def _mrel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
