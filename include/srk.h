@@ -100,17 +100,20 @@ int srk_conv3x3(const srk_conv_args* a, void* stream);
  * a DenseResidualBlock (models.py:34-41), whose buffers all exist before the first launch.  Stops at the first failing launch and
  * returns its status. */
 int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
-/* 16-bit storage (wp_format 7 / 8): a sequence in which every convolution takes at most its LAST 64 input channels from its predecessor's
- * output (a dense block: conv k reads slices 0..k-1 of one buffer and writes slice k), all of one geometry with <= 64 outputs and at
- * most one 16 x 32-pixel tile per CU, goes out as ONE persistent launch ("chain form": conv k+1's old slices stream in beside conv k's
- * last stage and stores, neighbouring tiles hand each other the new slice through device-scope flags).  Results are those of the
- * separate launches up to the order of the fp32 sums.  At most one chain kernel is in flight per device (launches on different
- * streams are ordered by an event).  A flag wait that runs into its 2 s limit does not hang: the NEXT srk_conv3x3_seq call returns
- * SRK_ERR_LAUNCH and the form is switched off.  SRK_H16_CHAIN=0 / srk_debug_set_h16_chain(0) disable it, 2 uses it wherever eligible
- * (default 1: where the 16-row kernel form would run).
+/* CHAIN FORMS (16-bit storage, wp_format 7 / 8; the fp32 F(2x4,3x3) kernel, wp_format 6): a sequence in which every convolution takes at
+ * most its LAST 64 input channels from its predecessor's output (a dense block: conv k reads slices 0..k-1 of one buffer and writes
+ * slice k), all of one geometry, 64-channel slices on 128-byte lines, 64 outputs, at most one workgroup tile per CU, goes out as ONE
+ * persistent launch: every workgroup keeps its tile for the whole sequence, neighbouring tiles hand each other the new slice through
+ * device-scope flags instead of a kernel boundary, and the next conv's first (old-slice) stage streams in beside the previous conv's
+ * end.  Results: wp_format 6 bit-identical to the separate launches; 7 / 8 identical up to the order of the fp32 sums (one unit in the
+ * last place of the 16-bit outputs).  At most one chain kernel is in flight per device (launches on different streams are ordered by
+ * an event).  A flag wait that runs into its 2 s limit does not hang: the NEXT srk_conv3x3_seq call returns SRK_ERR_LAUNCH and the
+ * forms are switched off.  SRK_H16_CHAIN=0 / SRK_W42_CHAIN=0 (srk_debug_set_h16_chain / _w42_chain(0)) disable them; for wp_format
+ * 7 / 8 the default (1) uses the form where the 16-row kernel would run, 2 wherever the sequence is eligible.
  * srk_conv3x3_seq_kernel_name: name of the one kernel the sequence goes to, "" if it is launched conv by conv. */
 int srk_conv3x3_seq_kernel_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_debug_set_h16_chain(int mode);
+int srk_debug_set_w42_chain(int mode);
 
 /* Weight-gradient of the same convolution:
  *   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]

@@ -1090,6 +1090,9 @@ int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len);
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st);   // 1: launched as one chain kernel, 0: not eligible, < 0: error
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n);
 int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
+int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st);   // the same for the fp32 F(2x4,3x3) kernel (wp_format 6)
+int srk_conv_w42_chain_would(const srk_conv_args* args, int n);
+int srk_conv_w42_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1172,9 +1175,11 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
 
 extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
   if (!args || n <= 0) return SRK_ERR_BAD_ARG;
-  {
-    // 16-bit storage: a dense block's sequence as ONE persistent launch (srk_conv_h16.hip, "the chain form")
-    const int rc = srk_launch_conv_h16_chain(args, n, (hipStream_t)stream);
+  if (n >= 2) {
+    // a dense block's sequence as ONE persistent launch (the chain forms: srk_chain.h; 16-bit storage and the fp32 F(2x4,3x3) kernel)
+    const int fmt = args[0].wp_format;
+    const int rc = (fmt == 7 || fmt == 8) ? srk_launch_conv_h16_chain(args, n, (hipStream_t)stream)
+                 : (fmt == 6 ? srk_launch_conv_w42_chain(args, n, (hipStream_t)stream) : 0);
     if (rc < 0) return rc;
     if (rc == 1) return SRK_OK;
   }
@@ -1190,7 +1195,10 @@ extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
 extern "C" int srk_conv3x3_seq_kernel_name(const srk_conv_args* args, int n, char* buf, size_t len) {
   if (!args || n <= 0 || !buf || len < 8) return SRK_ERR_BAD_ARG;
   buf[0] = 0;
-  if (srk_conv_h16_chain_would(args, n) == 1) return srk_conv_h16_chain_name(args, n, buf, len);
+  if (n < 2) return SRK_OK;
+  const int fmt = args[0].wp_format;
+  if ((fmt == 7 || fmt == 8) && srk_conv_h16_chain_would(args, n) == 1) return srk_conv_h16_chain_name(args, n, buf, len);
+  if (fmt == 6 && srk_conv_w42_chain_would(args, n) == 1) return srk_conv_w42_chain_name(args, n, buf, len);
   return SRK_OK;
 }
 

@@ -19,9 +19,9 @@
 // folded in); the residual / mask tensors are read the same way, 16 bytes per lane, all loads of a batch ahead of its stores.
 #include "srk_internal.h"
 #include "srk_epilogue.h"
+#include "srk_chain.h"
 #include <stdio.h>
 #include <stdlib.h>
-#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -693,16 +693,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
 // XCD (147 / 148, and correctness would hang on the workgroup -> XCD map); the MFMA waves only DUMPING the tile (16-bit, into the
 // free stage buffer) and four loader waves doing residuals / mask / stores beside the next conv's first stage (133 / 148: the
 // next stage's DMA then has to wait for the dump to be read out, which costs what the shorter epilogue saves).
-constexpr int H16_CHAIN_MAX = 8;
-struct h16_chain_args {
-  srk_conv_args c[H16_CHAIN_MAX];
-  int n;
-  unsigned epoch;
-  unsigned* flags;
-  unsigned* err;
-};
+typedef srk_chain_args h16_chain_args;
 #ifndef H16_CHAIN_ALL_DEV
 #define H16_CHAIN_ALL_DEV 0
+#endif
+#ifndef H16_CHAIN_FRESH_DEV
+#define H16_CHAIN_FRESH_DEV 1
 #endif
 #ifndef H16_CHAIN_SIG_STEP
 #define H16_CHAIN_SIG_STEP 12
@@ -740,22 +736,8 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
     const int lw = wv - 4;
     constexpr int NXJ = (G::HPIECES + H16_NLOAD - 1) / H16_NLOAD, NWJ = G::WPIECES / H16_NLOAD;
     const unsigned wvo = (unsigned)(lane * 16);
-    // the neighbour this lane watches (lanes 0..8; the tile itself and tiles outside the image need no wait)
-    const int ndy = lane / 3 - 1, ndx = lane % 3 - 1;
-    const bool watch = lane < 9 && lane != 4 && (unsigned)(ty + ndy) < (unsigned)tilesH && (unsigned)(tx + ndx) < (unsigned)tilesW;
-    const unsigned* fp = A.flags + (watch ? (n * tilesH + ty + ndy) * tilesW + tx + ndx : tile);
-    auto wait_flags = [&](unsigned target) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      for (;;) {
-        const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-        if (__all((int)(v - target) >= 0)) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter
-          if (lane == 0) __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    };
+    const srk_chain_watch watch = srk_chain_watch_of(A.flags, lane, n, ty, tx, tilesH, tilesW);     // lanes 0..8: the eight neighbouring tiles
+    auto wait_flags = [&](unsigned target) { srk_chain_wait(watch, target, A.err, lane); };
     unsigned xvo[NXJ];
     __amdgpu_buffer_rsrc_t xrs, wrs;
     int CoutP = 64;
@@ -806,7 +788,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
       __builtin_amdgcn_s_barrier();                       // this conv's stage 0 is in LDS; the epilogue scratch (buffer 1) is free
       for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) {
-          const bool fresh = c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
+          const bool fresh = H16_CHAIN_FRESH_DEV && c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
           if (c > 0 && q + 1 == nq - 2) { H16C_STAMP(256, c, 4); wait_flags(A.epoch + (unsigned)c); H16C_STAMP(256, c, 5); }
           stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && c > 0));
           if (c > 0 && q == 0 && lw == 0) {
@@ -1093,128 +1075,48 @@ int srk_conv_h16_check(const srk_conv_args& a) {
 // ------------------------------------------------------------------------------------------ the chain form: host side
 namespace {
 int g_h16_chain = -1;          // 0: never, 1: where the 16-row form would run (default), 2: wherever the sequence is eligible (tests)
-struct ChainDev {
-  unsigned* flags = nullptr;   // one word per tile (device)
-  unsigned* err = nullptr;     // pinned host word the kernel writes when a flag wait timed out
-  unsigned epoch = 0;
-  int cus = 0;
-  hipEvent_t ev = nullptr;     // end of the newest chain launch, once a second stream has shown up
-  hipStream_t last = nullptr;
-  bool used = false, multi = false, dead = false;
-};
-ChainDev g_chain_dev[16];
-std::mutex g_chain_mu;
-constexpr int H16_CHAIN_FLAGS = 1024;
-
-// do the channel ranges [ca, ca + na) of view (pa, lda) and [cb, cb + nb) of (pb, ldb) share memory?  (px pixels per tensor, 16-bit elements)
-bool h16_views_overlap(const void* pa, int lda, int ca, int na, const void* pb, int ldb, int cb, int nb, long px) {
-  if (na <= 0 || nb <= 0) return false;
-  if (pa == pb && lda == ldb) return ca < cb + nb && cb < ca + na;
-  const uintptr_t a0 = (uintptr_t)pa + 2u * (uintptr_t)ca, a1 = (uintptr_t)pa + 2u * ((uintptr_t)(px - 1) * lda + ca + na);
-  const uintptr_t b0 = (uintptr_t)pb + 2u * (uintptr_t)cb, b1 = (uintptr_t)pb + 2u * ((uintptr_t)(px - 1) * ldb + cb + nb);
-  return a0 < b1 && b0 < a1;
-}
-
-// Is args[0..n) a sequence the chain kernel runs?  (The dense-block pattern: every conv takes at most its LAST 64 input channels from its
-// predecessor's output, nothing from its own.)
-bool h16_chain_eligible(const srk_conv_args* args, int n, int mode, int cus) {
-  if (mode <= 0 || n < 2 || n > H16_CHAIN_MAX) return false;
-  const srk_conv_args& f = args[0];
-  if (f.wp_format != 7 && f.wp_format != 8) return false;
-  if (mode == 1 && srk_conv_h16_mt(f) != 4) return false;
-  const long tiles = (long)f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW);
-  if (tiles > cus || tiles > H16_CHAIN_FLAGS) return false;
-  const long px = (long)f.N * f.H * f.W;
-  for (int c = 0; c < n; ++c) {
-    const srk_conv_args& a = args[c];
-    if (srk_conv_h16_check(a) != SRK_OK) return false;
-    if (a.wp_format != f.wp_format || a.in_mode != SRK_IN_PLAIN || a.ps_out || (a.flags & SRK_CONV_OUT_F32)) return false;
-    if (a.N != f.N || a.H != f.H || a.W != f.W || a.Cout > 64 || (a.Cin % 64)) return false;
-    if (c > 0 && a.Cin < 128) return false;
-    if (h16_views_overlap(a.y, a.y_ldc, a.y_coff, a.Cout, a.x, a.x_ldc, a.x_coff, a.Cin, px)) return false;
-    if (c > 0) {
-      const srk_conv_args& p = args[c - 1];
-      if (h16_views_overlap(p.y, p.y_ldc, p.y_coff, p.Cout, a.x, a.x_ldc, a.x_coff, a.Cin - 64, px)) return false;
-    }
-  }
-  return true;
-}
-
 int h16_chain_mode() {
   if (g_h16_chain < 0) { const char* e = getenv("SRK_H16_CHAIN"); g_h16_chain = e ? atoi(e) : 1; }
   return g_h16_chain;
 }
-
-ChainDev* h16_chain_dev() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  ChainDev& D = g_chain_dev[dev];
-  if (!D.flags && !D.dead) {
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { D.dead = true; return nullptr; }
-    D.cus = pr.multiProcessorCount;
-    if (hipMalloc((void**)&D.flags, H16_CHAIN_FLAGS * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(D.flags, 0, H16_CHAIN_FLAGS * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void**)&D.err, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
-      (void)hipGetLastError();
-      D.dead = true; D.flags = nullptr;
-      return nullptr;
-    }
-    *D.err = 0;
+// Is args[0..n) a sequence the chain kernel runs?  (srk_chain_pattern_ok: the dense-block pattern; here: the 16-bit formats, one tile per CU at most)
+bool h16_chain_eligible(const srk_conv_args* args, int n, int mode) {
+  if (mode <= 0 || n < 2 || n > SRK_CHAIN_MAX) return false;
+  const srk_conv_args& f = args[0];
+  if (f.wp_format != 7 && f.wp_format != 8) return false;
+  if (mode == 1 && srk_conv_h16_mt(f) != 4) return false;
+  const long tiles = (long)f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW);
+  const int cus = srk_chain_cus();
+  if (cus <= 0 || tiles > cus || tiles > SRK_CHAIN_FLAGS) return false;
+  for (int c = 0; c < n; ++c) {
+    const srk_conv_args& a = args[c];
+    if (a.wp_format != f.wp_format || (a.flags & SRK_CONV_OUT_F32) || srk_conv_h16_check(a) != SRK_OK) return false;
   }
-  return D.dead ? nullptr : &D;
+  return srk_chain_pattern_ok(args, n, 2);
 }
 }  // namespace
 
 extern "C" int srk_debug_set_h16_chain(int mode) { g_h16_chain = (mode >= 0 && mode <= 2) ? mode : 1; return SRK_OK; }
 
-// 1: the sequence goes out as ONE chain launch; 0: not eligible (the caller launches the convs one by one); < 0: error
+// 1: the sequence goes out as ONE chain launch; 0: not eligible (the caller launches the convs one by one)
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n) {
-  const int mode = h16_chain_mode();
-  if (mode <= 0 || n < 2 || (args[0].wp_format != 7 && args[0].wp_format != 8)) return 0;
-  std::lock_guard<std::mutex> lk(g_chain_mu);
-  ChainDev* D = h16_chain_dev();
-  if (!D) return 0;
-  return h16_chain_eligible(args, n, mode, D->cus) ? 1 : 0;
+  return h16_chain_eligible(args, n, h16_chain_mode()) ? 1 : 0;
 }
 
+// 1: launched as one chain kernel, 0: not eligible (nothing launched), < 0: error
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) {
-  const int mode = h16_chain_mode();
-  if (mode <= 0 || n < 2 || (args[0].wp_format != 7 && args[0].wp_format != 8)) return 0;
-  std::lock_guard<std::mutex> lk(g_chain_mu);
-  ChainDev* D = h16_chain_dev();
-  if (!D) return 0;
-  if (*reinterpret_cast<volatile unsigned*>(D->err)) {
-    // a flag wait of an earlier chain launch ran into its time limit: that launch's results are not to be trusted
-    fprintf(stderr, "libsrk: a conv3x3 chain launch timed out waiting for a neighbouring tile (results of that launch are invalid); "
-                    "the chain form is now off for this device (SRK_H16_CHAIN=0 avoids it from the start)\n");
-    *D->err = 0;
-    D->dead = true;
-    return SRK_ERR_LAUNCH;
-  }
-  if (!h16_chain_eligible(args, n, mode, D->cus)) return 0;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }   // (the epoch would be baked into the graph)
-  // at most ONE chain kernel in flight per device: two of them, each holding part of the CUs and waiting for tiles that cannot become
-  // resident, would wait for each other.  One stream orders its launches by itself; from the first launch on a second stream on, every
-  // chain launch is followed by an event the next one (on whatever stream) waits for.
-  if (D->used && D->last != st) {
-    if (!D->ev && hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) != hipSuccess) return SRK_ERR_LAUNCH;
-    if (!D->multi) { if (hipEventRecord(D->ev, D->last) != hipSuccess) return SRK_ERR_LAUNCH; D->multi = true; }
-    if (hipStreamWaitEvent(st, D->ev, 0) != hipSuccess) return SRK_ERR_LAUNCH;
-  }
-  h16_chain_args A;
+  if (!h16_chain_eligible(args, n, h16_chain_mode())) return 0;
+  srk_chain_args A;
+  const int rc = srk_chain_begin(st, n, &A);
+  if (rc != 1) return rc;
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
-  A.n = n; A.epoch = D->epoch; A.flags = D->flags; A.err = D->err;
-  D->epoch += (unsigned)n;
   const srk_conv_args& f = args[0];
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
   if (f.wp_format == 7) hipLaunchKernelGGL(conv3x3_h16_chain_kernel<_Float16>, grid, dim3(H16_THREADS), 0, st, A);
   else hipLaunchKernelGGL(conv3x3_h16_chain_kernel<__bf16>, grid, dim3(H16_THREADS), 0, st, A);
-  SRK_CHECK_LAUNCH();
-  D->used = true; D->last = st;
-  if (D->multi && hipEventRecord(D->ev, st) != hipSuccess) return SRK_ERR_LAUNCH;
-  return 1;
+  const bool ok = hipGetLastError() == hipSuccess;
+  const int rc2 = srk_chain_end(st, ok);
+  return ok ? (rc2 ? rc2 : 1) : SRK_ERR_LAUNCH;
 }
 
 int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len) {

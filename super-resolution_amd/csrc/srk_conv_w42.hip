@@ -18,6 +18,7 @@
 // Per 8-channel chunk and wave: 96 MFMAs, 160 VALU (transform), 48 ds_read_b64, 24 buffer_load_dwordx2, 5 DMA pieces, 1 barrier.
 #include "srk_internal.h"
 #include "srk_epilogue.h"
+#include "srk_chain.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -52,8 +53,11 @@ __device__ unsigned long long* g_w42_stamps = nullptr;
 // of a ds_read_b64 (the minimum) -- conflict-free reads although patches step by two rows and four pixels.
 // NMT = M tiles per workgroup: 2 = the 32 x 16-pixel form described above; 1 = a 16 x 16-pixel form (12 accumulator tiles per wave,
 // half the MFMAs per weight load and per barrier) for launches whose 32-row tiles would leave CUs idle (batch 16 at 64 x 64).
-template <int MODE, int NMT>
-__device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
+// CHAIN: the body as one link of the chain kernel below (srk_chain.h): conv c of the launch A.  Its outputs are stored write-through
+// and published through the tile's flag; (c > 0) the chunks of its last 64 input channels are fetched behind the wait for the
+// neighbouring tiles' flags of conv c - 1.
+template <int MODE, int NMT, bool CHAIN = false>
+__device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0) {
   constexpr int TH = 16 * NMT, IH = TH + 2, IW = SRK_TW + 2;
   constexpr int HS4 = NMT == 2 ? 640 : 384;         // slots per k-half: 37 per row pair (17 resp. 9 pairs), padded to whole instructions
   constexpr int BUF4 = 2 * HS4;                     // 1280 float4 = 20 KB (NMT 2) / 768 = 12 KB (NMT 1) per chunk
@@ -62,7 +66,11 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   constexpr int SMEM4 = (EXSLOTS + 4) * 256;        // 144 KB / 80 KB: exchange + 4 x 4 KB epilogue scratch (>= 2 halo buffers)
   __shared__ float4 smem[SMEM4];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_ = threadIdx.x;
+  // (CHAIN: everything derived from the lane id is formed again for every conv -- hoisted out of the chain loop it stays live through
+  // the K loop, where there is not one register to spare: the allocator then spills accumulator tiles inside the loop)
+  if constexpr (CHAIN) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // = row position p of this wave
   const int hl = lane >> 5, l32 = lane & 31;
   const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
@@ -71,6 +79,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
     const int T = gridDim.x;                        // XCD-contiguous tile ranges (see wino4_body)
     if ((T & 7) == 0) bid = (bid & 7) * (T >> 3) + (bid >> 3);
   }
+  const int tile = bid;
   const int tx = bid % tilesW; bid /= tilesW;
   const int ty = bid % tilesH; bid /= tilesH;
   const int n = bid;
@@ -78,6 +87,9 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   const int CoutP = (a.Cout + 31) & ~31;
   const int nq = (a.Cin + 7) >> 3;
   W42_STAMP(0);
+  // CHAIN: the first DMA of a chunk of the last 64 channels (chunks nq - 8 ..) is piece 0 of chunk nq - 8, issued in chunk nq - 10
+  const int qwait = nq - 10;
+  bool waited_ok = true;
 
   // ---- halo DMA plan: instruction i = wv + 4 j (j = 0..4) fills slots 64 i .. 64 i + 63
   constexpr unsigned OOB = 0x80000000u;
@@ -302,11 +314,21 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   W42_SEG_RESET();
   {
     int q = 0;
+    if constexpr (CHAIN) {
+      // Two copies of the loop with the wait BETWEEN them: a conditional wait inside the loop costs spills and reloads around it in
+      // every iteration.  Scalar instructions only -- there is no vector register to spare (nq is a multiple of 8, >= 16 behind the
+      // first conv: host-checked).
+      for (; q < qwait; q += 2) {
+        chunk(q, I0{});
+        chunk(q + 1, I1{});
+      }
+      if (c > 0) waited_ok = srk_chain_wait_scalar(A->flags, n, ty, tx, tilesH, tilesW, A->epoch + (unsigned)c);
+    }
     for (; q + 1 < nq; q += 2) {
       chunk(q, I0{});
       chunk(q + 1, I1{});
     }
-    if (q < nq) chunk(q, I0{});
+    if constexpr (!CHAIN) { if (q < nq) chunk(q, I0{}); }      // (CHAIN: nq is even)
   }
   W42_SEG_END();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (empty) DMA pieces and weight loads
@@ -357,12 +379,33 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a) {
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
-  conv_epilogue<64, 2 * NMT, false, 16>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);
+  conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : 0>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);     // (16 = sc1: write-through)
   W42_STAMP(5);
+  if constexpr (CHAIN) {
+    // publish this conv of the tile: every wave has seen its (write-through) stores acknowledged by memory; the barrier also ends this
+    // conv's use of the LDS before the next one's first DMA.
+    // (Tried, same-box A/B on the dense block at 32 x 64 x 64, forward / data gradient; five launches 477 / 491 us, this form 455 / 470:
+    //  the next conv's first halo chunk issued in front of this epilogue 480 / 496, + its first weights 508 / 522, both behind the
+    //  epilogue 481 / 495, the flag raised inside the next conv's K loop instead of here 465 / 480 -- whatever stays live across the
+    //  conv boundary costs this kernel more in spills than the overlap returns.)
+    if (!waited_ok && lane == 0) __hip_atomic_store(A->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0 && c + 1 < A->n) __hip_atomic_store(A->flags + tile, A->epoch + (unsigned)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <int MODE, int NMT>
 __global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_args a) { wino42_body<MODE, NMT>(a); }
+
+// The chain form: a dense block's convolutions (forward or data gradient) in ONE persistent launch, one workgroup per tile for all of
+// them (srk_chain.h).  What it saves against five launches: the kernel boundaries and their tails -- workgroups finish a 40-chunk conv
+// up to 9 us apart, and a launch waits for its slowest tile where a chain link waits for its neighbours only.  Same arithmetic in the
+// same order: bit-identical results.
+template <int NMT>
+__global__ __launch_bounds__(256) void conv3x3_f32_wino42_chain_kernel(const srk_chain_args A) {
+  for (int c = 0; c < A.n; ++c) wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c);
+}
 
 }  // namespace
 
@@ -393,6 +436,56 @@ int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st) {
   }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
+}
+
+// ---- the chain form: host side
+static int g_w42_chain = -1;      // 0: never, 1 (default): wherever the sequence is eligible
+extern "C" int srk_debug_set_w42_chain(int mode) { g_w42_chain = (mode == 0 || mode == 1) ? mode : 1; return SRK_OK; }
+
+static bool w42_chain_eligible(const srk_conv_args* args, int n) {
+  if (g_w42_chain < 0) { const char* e = getenv("SRK_W42_CHAIN"); g_w42_chain = e ? atoi(e) : 1; }
+  if (g_w42_chain <= 0 || n < 2 || n > SRK_CHAIN_MAX || args[0].wp_format != 6) return false;
+  const srk_conv_args& f = args[0];
+  const int nmt = srk_conv_wino42_nmt(f);
+  const long tiles = (long)f.N * srk_div_up(f.H, 16 * nmt) * srk_div_up(f.W, SRK_TW);
+  const int cus = srk_chain_cus();
+  if (cus <= 0 || tiles > cus || tiles > SRK_CHAIN_FLAGS || !srk_chain_flags_uncached()) return false;      // (the kernel polls with scalar loads)
+  for (int c = 0; c < n; ++c) {
+    const srk_conv_args& a = args[c];
+    if (a.wp_format != 6 || a.Cout != 64 || srk_conv_wino42_nmt(a) != nmt || (((uintptr_t)a.wp) & 15)) return false;
+    // the epilogue's 16-byte path (the one that stores write-through): srk_epilogue.h `vec_out`
+    if (a.bias && (((uintptr_t)a.bias) & 15)) return false;
+    if (a.r1 && ((a.r1_ldc | a.r1_coff) & 3 || (((uintptr_t)a.r1) & 15))) return false;
+    if (a.r2 && ((a.r2_ldc | a.r2_coff) & 3 || (((uintptr_t)a.r2) & 15))) return false;
+    if (a.mask && ((a.m_ldc | a.m_coff) & 3 || (((uintptr_t)a.mask) & 15))) return false;
+    if ((long)a.H * a.W * a.x_ldc * 4 > 0x7fffffffL) return false;
+  }
+  return srk_chain_pattern_ok(args, n, 4);
+}
+
+int srk_conv_w42_chain_would(const srk_conv_args* args, int n) { return w42_chain_eligible(args, n) ? 1 : 0; }
+
+int srk_conv_w42_chain_name(const srk_conv_args* args, int n, char* buf, size_t len) {
+  (void)n;
+  snprintf(buf, len, "conv3x3_f32_wino42_chain_kernel<%d>", srk_conv_wino42_nmt(args[0]));
+  return SRK_OK;
+}
+
+// 1: launched as one chain kernel, 0: not eligible (nothing launched), < 0: error
+int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st) {
+  if (!w42_chain_eligible(args, n)) return 0;
+  srk_chain_args A;
+  const int rc = srk_chain_begin(st, n, &A);
+  if (rc != 1) return rc;
+  for (int c = 0; c < n; ++c) A.c[c] = args[c];
+  const srk_conv_args& f = args[0];
+  const int nmt = srk_conv_wino42_nmt(f);
+  const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16 * nmt) * srk_div_up(f.W, SRK_TW)));
+  if (nmt == 2) hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<2>, grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<1>, grid, dim3(256), 0, st, A);
+  const bool ok = hipGetLastError() == hipSuccess;
+  const int rc2 = srk_chain_end(st, ok);
+  return ok ? (rc2 ? rc2 : 1) : SRK_ERR_LAUNCH;
 }
 
 #ifdef SRK_STAMP

@@ -17,7 +17,7 @@ __device__ __forceinline__ const float* srk_sgpr_opaque(const float* p) {
 // "slots"), NBT = items per batch.  Straight-line code: every access is a buffer load / store through a per-image resource
 // whose out-of-range offsets (W_OOB: tile pixels outside the image, channels >= Cout) load 0 / store nothing, and the
 // slot roles are uniform coefficients instead of branches -- one basic block, so the compiler counts vmcnt exactly.
-template <int BN, int MT, bool ROWTILE, int NBT, int NS>
+template <int BN, int MT, bool ROWTILE, int NBT, int NS, int SAUX = 0>
 __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float* ls, int n, int oh0, int ow0,
                                                   int n0, int wv, int lane, bool interior) {
   constexpr int NTN = BN / 32, NG = NTN * MT, NI = NG * 4;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16
 #ifdef SRK_NO_STORE
       asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(off));
 #else
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, off, 0, SAUX);
 #endif
     }
   }
@@ -138,7 +138,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16
 
 // Fused epilogue shared by the conv kernels.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of M tile m
 // (rows 2wv, 2wv+1 of the m-th 8-row group), channel = n0 + 32t + l32.
-template <int BN, int MT, bool ROWTILE = false, int PF = 8, int PF2 = (PF > 4 ? PF / 2 : PF)>
+// SAUX = cache-policy bits of the 16-byte stores (0; the chain kernels write through to device scope, srk_chain.h: their host side
+// admits only calls that take the 16-byte path).
+template <int BN, int MT, bool ROWTILE = false, int PF = 8, int PF2 = (PF > 4 ? PF / 2 : PF), int SAUX = 0>
 __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float4* smem, int n, int oh0,
                                               int ow0, int n0, int wv, int lane, int lds_slot = -1) {
   constexpr int NTN = BN / 32;
@@ -177,10 +179,10 @@ __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&a
     // Batch depth PF when at most one of r1 / r2 / mask is present (the usual case: dense-block convs carry a bias only,
     // data-gradient convs a mask only), PF2 with two of them, 4 with all three: the prefetched values stay within ~4 PF floats.
     const int n_aux = (has_r1 ? 1 : 0) + (has_r2 ? 1 : 0) + (has_m ? 1 : 0);
-    if (n_aux == 0) conv_epilogue_vec<BN, MT, ROWTILE, PF, 0>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else if (n_aux == 1) conv_epilogue_vec<BN, MT, ROWTILE, PF, 1>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else if (n_aux == 2) conv_epilogue_vec<BN, MT, ROWTILE, PF2, 2>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else conv_epilogue_vec<BN, MT, ROWTILE, 4, 3>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
+    if (n_aux == 0) conv_epilogue_vec<BN, MT, ROWTILE, PF, 0, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
+    else if (n_aux == 1) conv_epilogue_vec<BN, MT, ROWTILE, PF, 1, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
+    else if (n_aux == 2) conv_epilogue_vec<BN, MT, ROWTILE, PF2, 2, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
+    else conv_epilogue_vec<BN, MT, ROWTILE, 4, 3, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
   } else {
     // scalar path (Cout not a multiple of 4, e.g. the F->1 tail conv, or unaligned views): one dword per lane
     const int y_rs = rowmul * a.y_ldc, y_cs = colmul * a.y_ldc;

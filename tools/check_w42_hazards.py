@@ -61,7 +61,7 @@ def main():
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
-            inside = "wino42_kernel" in m.group(1)
+            inside = "wino42_kernel" in m.group(1) or "wino42_chain_kernel" in m.group(1)
             prev, vmem, last_wait = [], [], None
             continue
         if not inside:

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Chain form of the 16-bit conv (one persistent launch per dense block) against the same sequence launched conv by conv:
-results (max |diff| in units of the output scale) on several geometries, repeated to catch ordering races, then timing at
-BASELINE configs[4]'s trunk geometry.  FMT=7|8, REPS."""
+"""Chain forms of the conv kernels (one persistent launch per dense block) against the same sequence launched conv by conv:
+results (max |diff|) on several geometries, repeated to catch ordering races, then timing at the trunk geometry of the workload
+(FMT=7|8: 16-bit storage, BASELINE configs[4], 8 x 128 x 128; FMT=6: the fp32 F(2x4,3x3) kernel, headline, 32 x 64 x 64 -- there the
+two paths run the same arithmetic in the same order and must agree bit for bit).  REPS, N/HW override the timing geometry."""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 L = importlib.import_module("super-resolution_amd")._lib
 fmt = int(os.environ.get("FMT", 7))
-dt = {7: torch.float16, 8: torch.bfloat16}[fmt]
+dt = {6: torch.float32, 7: torch.float16, 8: torch.bfloat16}[fmt]
+set_chain = L.lib().srk_debug_set_w42_chain if fmt == 6 else L.lib().srk_debug_set_h16_chain
+FORCE = 1 if fmt == 6 else 2
 F = 64
 
 
@@ -46,7 +49,7 @@ def make_block(N, H, W, seed, backward=False):
 
 
 def run(calls, mode):
-    L.lib().srk_debug_set_h16_chain(mode)
+    set_chain(mode)
     L.conv3x3_seq(calls)
 
 
@@ -58,7 +61,7 @@ def check(N, H, W, reps, backward):
     worst = 0.0
     for r in range(reps):
         D[..., F:] = 0; out.zero_()
-        run(calls, 2)
+        run(calls, FORCE)
         torch.cuda.synchronize()
         d = max((D.float() - refD.float()).abs().max().item(), (out.float() - refO.float()).abs().max().item())
         worst = max(worst, d)
@@ -86,12 +89,13 @@ def timing(N, H, W, backward):
 if __name__ == "__main__":
     reps = int(os.environ.get("REPS", 5))
     bad = 0
-    for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (8, 128, 128)):
+    TN, THW = int(os.environ.get("N", 32 if fmt == 6 else 8)), int(os.environ.get("HW", 64 if fmt == 6 else 128))
+    for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (TN, THW, THW)):
         for bw in (False, True):
             r = check(N, H, W, reps if N < 8 else 3 * reps, bw)
-            bad += r > 4e-3
+            bad += r > (0.0 if fmt == 6 else 4e-3)
     print("MISMATCH" if bad else "results agree", flush=True)
     if not bad and not os.environ.get("NO_TIMING"):
-        timing(8, 128, 128, False)
-        timing(8, 128, 128, True)
+        timing(TN, THW, THW, False)
+        timing(TN, THW, THW, True)
     sys.exit(1 if bad else 0)
