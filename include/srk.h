@@ -301,6 +301,25 @@ int srk_conv3x3_wgrad_flat(const void* x, int ldc_in, int c_in_off, int Cin, con
                            int pixel_shuffle_r, int dtype, void* workspace, size_t ws_bytes, void* stream);
 /* (srk_conv3x3_wgrad / srk_conv3x3_wgrad_batched above are the struct forms the engine uses: packed dense-block batches) */
 
+/* torch.optim.Adam.step() of a whole parameter list in ONE launch (esrgan.py:299,305,487,623: the generator's and the discriminators'
+ * optimizers): fp32 parameters, gradients, exp_avg, exp_avg_sq behind a device table of pointers.  Arithmetic of ATen's fused Adam
+ * (amsgrad off, maximize off): g /= *grad_scale (if given); g += weight_decay * p; exp_avg = lerp(exp_avg, g, 1 - beta1);
+ * exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) g^2; p -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps) with
+ * t = *step (device, already incremented by the caller); nothing is touched when *found_inf != 0 (torch.amp.GradScaler's contract).
+ * srk_adam_plan fills chunk_begin of a host table and returns the launch size; the caller copies the table to the device. */
+typedef struct srk_adam_entry {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+  int64_t chunk_begin;
+} srk_adam_entry;
+int srk_adam_plan(srk_adam_entry* host_entries, int n, int64_t* total_chunks);
+int srk_adam_step(const srk_adam_entry* device_entries, int n, int64_t total_chunks, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
+/* n <= 64 tensors from the HOST table itself (it travels in the kernel arguments: nothing to copy when the gradients are new tensors
+ * every step, as a discriminator's are) */
+int srk_adam_step_small(const srk_adam_entry* host_entries, int n, int64_t total_chunks, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
+
 const char* srk_strerror(int status);
 int srk_version(void);
 

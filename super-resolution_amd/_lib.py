@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -63,6 +63,10 @@ class PackEntry(C.Structure):
     ]
 
 
+class AdamEntry(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_int64), ("chunk_begin", C.c_int64)]
+
+
 _lib = None
 
 
@@ -91,6 +95,9 @@ def lib():
         L.srk_debug_set_h16_mt.argtypes = [C.c_int]
         L.srk_pack_weights_h16.argtypes = [_fp, C.c_int, C.c_int64, C.c_int, _fp]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
+        L.srk_adam_plan.argtypes = [C.POINTER(AdamEntry), C.c_int, C.POINTER(C.c_int64)]
+        L.srk_adam_step.argtypes = [_fp, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
+        L.srk_adam_step_small.argtypes = [C.POINTER(AdamEntry), C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
         L.srk_conv3x3_seq.argtypes = [C.POINTER(ConvArgs), C.c_int, _fp]
         L.srk_conv3x3_seq_kernel_name.argtypes = [C.POINTER(ConvArgs), C.c_int, C.c_char_p, C.c_size_t]
         L.srk_debug_set_h16_chain.argtypes = [C.c_int]
@@ -508,3 +515,30 @@ def lrelu_grad_mul(x, g, out, slope):
     if not (x.is_contiguous() and g.is_contiguous() and out.is_contiguous()) or x.numel() != g.numel() or out.numel() != g.numel():
         raise ValueError("lrelu_grad_mul: contiguous tensors of equal size expected")
     check(lib().srk_lrelu_grad_mul(x.data_ptr(), g.data_ptr(), out.data_ptr(), g.numel(), float(slope), stream_ptr()), "srk_lrelu_grad_mul")
+
+
+class AdamTable:
+    """The pointer table of one srk_adam_step launch: rows (param, grad, exp_avg, exp_avg_sq addresses, numel) of fp32 tensors.  Up to 64
+    rows travel in the kernel arguments; a larger table is copied to the device once, through pinned memory on the launching stream."""
+
+    def __init__(self, device, rows):
+        n = len(rows)
+        arr = (AdamEntry * n)()
+        for e, (p, g, m, v, numel) in zip(arr, rows):
+            e.p, e.g, e.m, e.v, e.n = p, g, m, v, numel
+        total = C.c_int64(0)
+        check(lib().srk_adam_plan(arr, n, C.byref(total)), "srk_adam_plan")
+        self._host, self._n, self._total, self._dev = arr, n, total.value, None
+        if n > 64:
+            self._pin = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+            self._dev = torch.empty(self._pin.numel(), dtype=torch.uint8, device=device)
+            self._dev.copy_(self._pin, non_blocking=True)
+
+    def run(self, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, found_inf=None):
+        """step: fp32 device scalar holding the step number of THIS update"""
+        if self._dev is None:
+            check(lib().srk_adam_step_small(self._host, self._n, self._total, lr, beta1, beta2, eps, weight_decay, step.data_ptr(),
+                                            ptr(grad_scale), ptr(found_inf), stream_ptr()), "srk_adam_step_small")
+            return
+        check(lib().srk_adam_step(self._dev.data_ptr(), self._n, self._total, lr, beta1, beta2, eps, weight_decay, step.data_ptr(),
+                                  ptr(grad_scale), ptr(found_inf), stream_ptr()), "srk_adam_step")

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from . import losses, models, ops
+from . import losses, models, ops, optim
 
 EPS = 1e-7   # esrgan.py:319
 
@@ -98,9 +98,12 @@ class Stepper:
                                               power=scaling_power, multiplier=multiplier, num_final_layer_res=num_final_layer_res,
                                               uniform_init=uniform_init, drop_rate=drop_rate, use_transposed_conv=use_transposed_conv,
                                               fully_tconv_upsample=fully_tconv_upsample).to(device)
-        # esrgan.py:299,305: Adam(lr_g or lr), Adam(lr_d or lr); fused=True is the same arithmetic in one launch
-        self.optimizer_G = torch.optim.Adam([p for p in self.generator.parameters() if p.requires_grad],
-                                            lr=lr_g if lr_g > 0 else lr, betas=betas, weight_decay=weight_decay, fused=True)
+        # esrgan.py:299,305: Adam(lr_g or lr), Adam(lr_d or lr); optim.Adam = torch.optim.Adam's arithmetic in ONE launch over a pointer
+        # table (ATen's fused multi-tensor form: 20 launches, 1.5 ms for the generator's 702 tensors); SRK_TORCH_ADAM=1 restores ATen's
+        Adam = (lambda ps, **kw: torch.optim.Adam(ps, fused=True, **kw)) if os.environ.get("SRK_TORCH_ADAM", "0") == "1" else optim.Adam
+        self._Adam = Adam
+        self.optimizer_G = Adam([p for p in self.generator.parameters() if p.requires_grad],
+                                lr=lr_g if lr_g > 0 else lr, betas=betas, weight_decay=weight_decay)
         self.criterion_pixel = nn.L1Loss()
         self.criterion_GAN = nn.BCEWithLogitsLoss()
         self.mse = nn.MSELoss()
@@ -117,7 +120,7 @@ class Stepper:
                     else:
                         D = models.Markovian_Discriminator(input_shape=(channels, *hr_shape), channels=list(d_channels)).to(device)
                     self.discriminators[k] = D
-                    self.optimizer_D[k] = torch.optim.Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas, fused=True)
+                    self.optimizer_D[k] = self._Adam(D.parameters(), lr=lr_d if lr_d > 0 else lr, betas=betas)
         if distributed and not self.generator.modulewise:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         if distributed:
