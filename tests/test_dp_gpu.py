@@ -145,3 +145,88 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path, schedule):
     assert torch.isfinite(ranks[0]["nan_probe"]).all() and torch.isfinite(ranks[1]["nan_probe"]).all() and upd_ref.abs().max() > 0
     # NaN guard (esrgan.py:645-648) on an all-reduced flag: rank 1's NaN input makes the probe NaN on rank 0 too
     assert torch.isnan(ranks[0]["nan_probe_poisoned"]).all() and torch.isnan(ranks[1]["nan_probe_poisoned"]).all()
+
+
+# ---------------------------------------------------------------- BASELINE configs[4] under data parallelism (fp16 storage, loss scaling)
+C4_KEYS = ("conv1.weight", "res_blocks.0.dense_blocks.1.b3.0.weight", "res_blocks.0.dense_blocks.2.b5.0.bias", "upsampling.0.weight", "conv3.2.weight")
+
+
+def _c4_stepper(distributed):
+    train = importlib.import_module("super-resolution_amd.train")
+    st = train.Stepper(workload="g_only", res_blocks=1, filters=64, device=torch.device("cuda", 0), hr=64, factor=2, res_scale=0.2, channels=3,
+                       distributed=distributed)
+    st.generator._engine.precision = "fp16"
+    st.generator.load_state_dict(O.closed_form_fill({k: v.cpu() for k, v in st.generator.state_dict().items()}))
+    return st
+
+
+def _c4_inputs(world):
+    g = torch.Generator().manual_seed(11)
+    hr = torch.rand(2 * world, 3, 64, 64, generator=g)
+    return torch.nn.functional.avg_pool2d(hr, 2), hr
+
+
+def _c4_run(st, lr, hr):
+    res = {}
+    out = st.step(lr.cuda(), hr.cuda())                       # warm-up iteration: forward, scaled backward (+ all-reduce), unscale, Adam
+    named = dict(st.generator.named_parameters())
+    res["loss"] = out["g_loss"].detach().cpu()
+    res["scale"] = st._grad_scaler.get_scale()
+    # p.grad still holds the (loss-scaled) gradients the optimizer consumed
+    res["grads"] = {k: (named[k].grad.detach() / res["scale"]).cpu().clone() for k in C4_KEYS}
+    out = st.step(lr.cuda(), hr.cuda())
+    res["loss2"] = out["g_loss"].detach().cpu()
+    res["after"] = {k: named[k].detach().cpu().clone() for k in C4_KEYS}
+    return res
+
+
+def _c4_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        st = _c4_stepper(True)
+        assert st.generator._engine._sync
+        lr, hr = _c4_inputs(world)
+        sl = slice(2 * rank, 2 * rank + 2)
+        torch.save(_c4_run(st, lr[sl], hr[sl]), os.path.join(outdir, f"c4rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp16_storage_warmup_two_ranks_equal_one_process(tmp_path):
+    """configs[4]'s path (16-bit activation storage, dynamic loss scaling) as two data-parallel ranks against one process on the whole
+    batch: the all-reduced (still loss-scaled) gradients are identical on both ranks, the unscaled gradients and the weights after two
+    Adam steps agree with the single process within the storage format's rounding, and both ranks keep the same loss scale."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = 27000 + (os.getpid() % 3000)
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    st = _c4_stepper(False)
+    lr, hr = _c4_inputs(world)
+    ref = _c4_run(st, lr, hr)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+    ranks = [torch.load(os.path.join(str(tmp_path), f"c4rank{r}.pt")) for r in range(world)]
+    assert ranks[0]["scale"] == ranks[1]["scale"] == ref["scale"] == 65536.0
+    assert _rel((ranks[0]["loss"] + ranks[1]["loss"]).reshape(1) / 2, ref["loss"].reshape(1)) < 1e-3
+    assert _rel((ranks[0]["loss2"] + ranks[1]["loss2"]).reshape(1) / 2, ref["loss2"].reshape(1)) < 1e-3
+    for k in C4_KEYS:
+        assert torch.equal(ranks[0]["grads"][k], ranks[1]["grads"][k]), k
+        assert torch.equal(ranks[0]["after"][k], ranks[1]["after"][k]), k
+        # two half batches in fp16 storage vs the whole batch: different rounding of the 16-bit gradient buffers, same gradient
+        assert _rel(ranks[0]["grads"][k], ref["grads"][k]) < 2e-2, k
+        upd, upd_ref = ranks[0]["after"][k] - O_fill(st, k), ref["after"][k] - O_fill(st, k)
+        assert ((upd - upd_ref).abs().mean() / upd_ref.abs().mean().clamp_min(1e-12)).item() < 0.1, k
+
+
+def O_fill(st, key):
+    """the closed-form initial value of a generator tensor (what both runs started from)"""
+    sd = O.closed_form_fill({k: v.cpu() for k, v in st.generator.state_dict().items()})
+    return sd[key]
