@@ -130,3 +130,52 @@ def test_wino42_chain_eligibility(U):
     assert _seq_kernel(L, calls2) == ""
     L.lib().srk_debug_set_w42_chain(0)
     assert _seq_kernel(L, calls) == ""
+
+
+def test_chain_launches_from_two_streams_are_ordered_by_the_library(U):
+    """At most one chain kernel may be in flight per device (two of them could each hold part of the CUs and wait for tiles that cannot
+    become resident).  Sequences issued alternately on two streams -- the library orders them with an event -- give the single-stream
+    results, at the full trunk geometry where a launch needs every CU."""
+    L = U.L
+    blocks = [_block(U, 32, 64, 64, bw, 950 + i) for i, bw in enumerate((False, True))]
+    refs = []
+    for D, out, calls, keep in blocks:
+        L.conv3x3_seq(calls)
+        torch.cuda.synchronize()
+        refs.append((D.clone(), out.clone()))
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(6):
+        for (D, out, calls, keep) in blocks:
+            D[..., F_:] = 0
+            out.zero_()
+        torch.cuda.synchronize()
+        for i, (D, out, calls, keep) in enumerate(blocks):
+            with torch.cuda.stream(s[(i + rep) & 1]):
+                L.conv3x3_seq(calls)
+                L.conv3x3_seq(calls)          # (idempotent: same inputs, same outputs)
+        torch.cuda.synchronize()
+        for (D, out, calls, keep), (rD, rO) in zip(blocks, refs):
+            assert torch.equal(D, rD) and torch.equal(out, rO)
+
+
+def test_chain_form_is_skipped_under_stream_capture(U):
+    """the launch epoch is a kernel argument: a captured graph must hold the conv-by-conv launches (which replay correctly)"""
+    L = U.L
+    D, out, calls, keep = _block(U, 2, 64, 48, False, 960)
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    refD, refO = D.clone(), out.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        D[..., F_:] = 0
+        out.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            L.conv3x3_seq(calls)
+    for rep in range(3):
+        D[..., F_:] = 0
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(D, refD) and torch.equal(out, refO)
