@@ -30,6 +30,13 @@ typedef __bf16 h16_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float h16_f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
 
+// Cache-policy bits of the one-conv kernels' 16-byte output stores: 16 = sc1, write-through.  Outputs kept dirty in the L2 displace the
+// weights and halo rows the other workgroups of the XCD are about to read: a dense block as five launches takes 160 us with plain
+// stores, 153 with sc1 or nt (data gradients: 168 either way); the chain form with plain stores for the tile interior 164 instead of 135.
+#ifndef H16_STORE_AUX
+#define H16_STORE_AUX 16
+#endif
+
 namespace {
 
 #ifdef SRK_STAMP       // diagnostic build only (make stamp; tools/stamp_h16.py): phase stamps of wave 0 of every workgroup
@@ -87,8 +94,9 @@ template <int MT> struct HGeo {
 // ------------------------------------------------------------------------------------------------------------------ epilogue
 // acc[m][t][reg]: output row MT wv + m of the tile, pixel i = (reg & 3) + 8 (reg >> 2) + 4 hl of that row, channel n0 + 32 t + l32.
 // Item (m, j), j = 0..3: pixel pl = 8 j + (lane >> 3), channels n0 + 8 (lane & 7) .. + 7.  NS = how many of r1 / r2 / mask exist.
-// SAUX = cache-policy bits of the stores (0; the chain form writes through to device scope, see below).
-template <typename T, int MT, int NS, bool OUTF32, int SAUX = 0>
+// SAUX = cache-policy bits of the stores (0; the chain form writes through to device scope, see below).  BORDER: write through only what
+// another tile reads -- the outermost pixel ring of the MT*4 x 32 tile (18 % of it); the interior is re-read by this tile's own CU only.
+template <typename T, int MT, int NS, bool OUTF32, int SAUX = 0, bool BORDER = false>
 __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][2], float* ls, int n, int oh0, int ow0, int n0, int wv, int lane) {
   typedef typename H16<T>::v8 v8;
   constexpr int TB = OUTF32 ? 1 : (NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1));    // M tiles per batch (loads ahead of stores)
@@ -233,7 +241,20 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
           for (int e = 0; e < 8; ++e) ov[e] = o[e];
           const v8 hv = __builtin_convertvector(ov, v8);
           const unsigned off = ok ? (unsigned)(pix[mm][j] * a.y_ldc + ch) * (unsigned)YB : H_OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
+          if constexpr (!BORDER) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
+          } else {
+            const int row = MT * wv + m;                           // (wave-uniform)
+            if (row == 0 || row == 4 * MT - 1) {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
+            } else if (j == 0 || j == 3) {                         // columns 0 (plb == 0 of j == 0) and 31 (plb == 7 of j == 3)
+              const bool edge = j == 0 ? plb == 0 : plb == 7;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, edge ? off : H_OOB, 0, SAUX);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, edge ? H_OOB : off, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, 0);
+            }
+          }
         }
       }
     }
@@ -471,10 +492,10 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
   if constexpr (OUTF32) {
     h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
   } else {
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else h16_epilogue<T, MT, 3, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
   }
   H16_STAMP(4);
 #ifdef SRK_STAMP
@@ -662,10 +683,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
   if constexpr (OUTF32) {
     h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
   } else {
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else h16_epilogue<T, MT, 3, false>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
   }
 }
 
@@ -699,6 +720,9 @@ typedef srk_chain_args h16_chain_args;
 #endif
 #ifndef H16_CHAIN_FRESH_DEV
 #define H16_CHAIN_FRESH_DEV 1
+#endif
+#ifndef H16_CHAIN_BORDER
+#define H16_CHAIN_BORDER 0       // 1: write through only the tile's outermost pixel ring (what other tiles read) -- measured 164 / 159 us instead of 135 / 142
 #endif
 #ifndef H16_CHAIN_SIG_STEP
 #define H16_CHAIN_SIG_STEP 12
@@ -926,10 +950,10 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     H16C_STAMP(0, c, 1);
     const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else h16_epilogue<T, MT, 3, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    else h16_epilogue<T, MT, 3, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
     H16C_STAMP(0, c, 2);
     sig_pending = c + 1 < nconv;
   }

@@ -28,6 +28,9 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W42_STORE_AUX
+#define W42_STORE_AUX 0          // cache-policy bits of the one-conv kernels' 16-byte stores (A/B builds: 2 = nt, 16 = sc1)
+#endif
 #ifndef W42_XA
 #define W42_XA 2         // the gap (relative to the first transform slot of a phase) that holds the input transform
 #endif
@@ -379,7 +382,7 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
-  conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : 0>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);     // (16 = sc1: write-through)
+  conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : W42_STORE_AUX>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);     // (16 = sc1: write-through)
   W42_STAMP(5);
   if constexpr (CHAIN) {
     // publish this conv of the tile: every wave has seen its (write-through) stores acknowledged by memory; the barrier also ends this
