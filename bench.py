@@ -210,6 +210,11 @@ def main():
     backend = os.environ.get("SRK_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks sharing one GPU (RCCL refuses that)
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
+        if world > torch.cuda.device_count():
+            # several ranks on ONE GPU: a chain kernel needs every CU of the device for itself (csrc/srk_chain.h keeps one in flight per
+            # PROCESS); two processes' chain kernels would each hold part of the CUs and run into the bounded wait
+            os.environ.setdefault("SRK_W42_CHAIN", "0")
+            os.environ.setdefault("SRK_H16_CHAIN", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sr = importlib.import_module("super-resolution_amd")
