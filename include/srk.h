@@ -107,7 +107,7 @@ int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
  * device-scope flags instead of a kernel boundary, and the next conv's first (old-slice) stage streams in beside the previous conv's
  * end.  Results: wp_format 6 bit-identical to the separate launches; 7 / 8 identical up to the order of the fp32 sums (one unit in the
  * last place of the 16-bit outputs).  At most one chain kernel is in flight per device (launches on different streams are ordered by
- * an event).  A flag wait that runs into its 2 s limit does not hang: the NEXT srk_conv3x3_seq call returns SRK_ERR_LAUNCH and the
+ * an event).  A flag wait that runs into its 30 s limit does not hang: the NEXT srk_conv3x3_seq call returns SRK_ERR_LAUNCH and the
  * forms are switched off.  SRK_H16_CHAIN=0 / SRK_W42_CHAIN=0 (srk_debug_set_h16_chain / _w42_chain(0)) disable them; for wp_format
  * 7 / 8 the default (1) uses the form where the 16-row kernel would run, 2 wherever the sequence is eligible.
  * srk_conv3x3_seq_kernel_name: name of the one kernel the sequence goes to, "" if it is launched conv by conv. */

@@ -6,7 +6,8 @@
 // instead of through a kernel boundary.  Rules every form keeps:
 //   * at most one workgroup per CU (host-checked against the device) and at most ONE chain kernel in flight per device (the host
 //     orders launches on different streams by an event): no workgroup waits for a tile that cannot become resident;
-//   * a tile publishes conv k before it waits for anybody's conv k (no cycle), and every wait is bounded (2 s): on a time-out the
+//   * a tile publishes conv k before it waits for anybody's conv k (no cycle), and every wait is bounded (SRK_CHAIN_WAIT_TICKS = 30 s: an all-reduce kernel holding CUs while a peer rank
+//     is seconds late must not trip it): on a time-out the
 //     kernel sets *err and goes on, so it always drains; the host turns the word into an error on its next call and switches the
 //     chain forms off;
 //   * a conv reads from its predecessor's output only through its LAST 64 input channels, fetched behind the wait; nobody reads a
@@ -17,6 +18,7 @@
 
 constexpr int SRK_CHAIN_MAX = 8;          // convolutions per launch
 constexpr int SRK_CHAIN_FLAGS = 1024;     // tiles per launch (>= CUs of the device)
+constexpr unsigned long long SRK_CHAIN_WAIT_TICKS = 3000000000ull;     // 30 s of the 100 MHz s_memrealtime counter
 
 struct srk_chain_args {
   srk_conv_args c[SRK_CHAIN_MAX];
@@ -40,13 +42,13 @@ __device__ __forceinline__ srk_chain_watch srk_chain_watch_of(const unsigned* fl
   w.fp = flags + (w.on ? (n * tilesH + ty + ndy) * tilesW + tx + ndx : (n * tilesH + ty) * tilesW + tx);
   return w;
 }
-// wave-wide: returns once every watched flag has reached `target` (or after 2 s, with *err set)
+// wave-wide: returns once every watched flag has reached `target` (or after the time limit, with *err set)
 __device__ __forceinline__ void srk_chain_wait(const srk_chain_watch& w, unsigned target, unsigned* err, int lane) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     const unsigned v = w.on ? __hip_atomic_load(w.fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
     if (__all((int)(v - target) >= 0)) break;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter
+    if (__builtin_amdgcn_s_memrealtime() - t0 > SRK_CHAIN_WAIT_TICKS) {
       if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
@@ -69,7 +71,7 @@ __device__ __forceinline__ bool srk_chain_wait_scalar(const unsigned* flags, int
       unsigned v;
       asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(fp) : "memory");
       if ((int)(v - target) >= 0) break;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { ok = false; break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > SRK_CHAIN_WAIT_TICKS) { ok = false; break; }
       __builtin_amdgcn_s_sleep(4);
     }
   }

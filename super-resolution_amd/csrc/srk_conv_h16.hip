@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
 //     Every other load touches data that predates the launch, or that this XCD cannot hold a stale copy of (nobody reads a slice
 //     before it is written, and its first reads are the sc1 ones); H16_CHAIN_ALL_DEV makes every halo load of convs >= 1 sc1.
 // No workgroup ever waits for a tile that is not resident or on its way: the grid is at most one workgroup per CU (host-checked)
-// and the library keeps at most one chain kernel in flight per device.  A wait that still runs into the time limit (2 s) sets
+// and the library keeps at most one chain kernel in flight per device.  A wait that still runs into the time limit (30 s) sets
 // *err and goes on -- the kernel always drains; the host turns that into an error on the next call.
 // Tried and dropped (tools/debug/chain_check.py, 8 x 128 x 128, forward / data-gradient block; five launches: 158 / 168 us; this
 // form: 138 / 143): plain stores + buffer_wbl2 before the flag (171 / 164); plain stores and loads where whole images fall to one
