@@ -91,9 +91,21 @@ typedef struct srk_conv_args {
                                   wp = fragments of srk_pack_entry.fmt 7 / 8; stride 1, Cin % 32 == 0, Cout % 8 == 0, plain / unshuffle
                                   input, in_slope == 1 */
   int32_t flags;            /* SRK_CONV_OUT_F32: (wp_format 7 / 8 only) y is fp32 [.., y_ldc] (y_ldc / y_coff in fp32 elements, any Cout);
-                               excludes r1 / r2 / mask / ps_out -- the generator's last conv writes the fp32 image */
+                               excludes r1 / r2 / mask / ps_out -- the generator's last conv writes the fp32 image
+                               SRK_CONV_WRITE_SIGNS / SRK_CONV_MASK_SIGNS: see `signs` */
+  void* signs;              /* SIGN BITS of an output tensor (wp_format 7 / 8, 16-bit output, no ps_out; srk_conv3x3_signs_bytes() bytes, 16-byte
+                               aligned, layout private to the kernels: 128 bits per lane of a workgroup tile).  SRK_CONV_WRITE_SIGNS: besides
+                               y, the conv writes (y > 0) per stored element here.  SRK_CONV_MASK_SIGNS: the LeakyReLU' mask comes from such
+                               bits, written by an earlier conv of the SAME geometry (N, OH, OW, Cout) and format, instead of from `mask`
+                               (which must be NULL): the data-gradient conv of a dense block then reads 1 MB instead of the 16.8 MB of the
+                               forward activation.  Same results as with the mask tensor.  (The fp32 F(2x4,3x3) kernel does not offer them:
+                               it has no register to spare.) */
 } srk_conv_args;
 #define SRK_CONV_OUT_F32 1
+#define SRK_CONV_WRITE_SIGNS 2
+#define SRK_CONV_MASK_SIGNS 4
+/* bytes of the `signs` buffer for this conv (by its geometry, format and the kernel form its launch takes); 0: the launch does not support sign bits */
+size_t srk_conv3x3_signs_bytes(const srk_conv_args* a);
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
 /* n of them launched back to back on `stream`, in array order, from ONE call: the five forward (or five data-gradient) convolutions of

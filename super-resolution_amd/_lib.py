@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3_signs_bytes", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -41,6 +41,7 @@ class ConvArgs(C.Structure):
         ("slope", C.c_float),
         ("mask", _fp), ("m_ldc", C.c_int32), ("m_coff", C.c_int32), ("mask_slope", C.c_float),
         ("wp_format", C.c_int32), ("flags", C.c_int32),
+        ("signs", _fp),
     ]
 
 
@@ -95,6 +96,8 @@ def lib():
         L.srk_debug_set_h16_mt.argtypes = [C.c_int]
         L.srk_pack_weights_h16.argtypes = [_fp, C.c_int, C.c_int64, C.c_int, _fp]
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
+        L.srk_conv3x3_signs_bytes.restype = C.c_size_t
+        L.srk_conv3x3_signs_bytes.argtypes = [C.POINTER(ConvArgs)]
         L.srk_adam_plan.argtypes = [C.POINTER(AdamEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_adam_step.argtypes = [_fp, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
         L.srk_adam_step_small.argtypes = [C.POINTER(AdamEntry), C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
@@ -159,6 +162,7 @@ def ptr(t):
 
 
 CONV_OUT_F32 = 1
+CONV_WRITE_SIGNS, CONV_MASK_SIGNS = 2, 4
 FMT_OF_DTYPE = {torch.float16: 7, torch.bfloat16: 8}       # wp_format / pack fmt of the 16-bit-storage kernels
 WGRAD_PRECISION_OF_DTYPE = {torch.float16: 3, torch.bfloat16: 4}
 
@@ -220,9 +224,18 @@ def _conv_kernel_name(a) -> str:
 
 def _fill_conv_args(a, x: View, wp, bias, y: View, *, N, H, W, OH, OW, Cin, Cout, stride=1, in_mode=IN_PLAIN,
                     ps_out=False, alpha=1.0, r1: View = None, beta1=0.0, r2: View = None, beta2=0.0, slope=1.0,
-                    mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0, flags=0):
+                    mask: View = None, mask_slope=1.0, in_slope=1.0, wp_format=0, flags=0, signs_out=None, mask_signs=None):
+    """signs_out: uint8 tensor of conv_signs_bytes(...) bytes that receives the sign bits of y (srk_conv_args.signs, SRK_CONV_WRITE_SIGNS);
+    mask_signs: such a tensor used as the LeakyReLU' mask (SRK_CONV_MASK_SIGNS; mask_slope applies)"""
     a.in_slope = in_slope
     a.wp_format = getattr(wp, "fmt", wp_format)
+    if signs_out is not None:
+        flags |= CONV_WRITE_SIGNS
+        a.signs = signs_out.data_ptr()
+    if mask_signs is not None:
+        flags |= CONV_MASK_SIGNS
+        a.signs = mask_signs.data_ptr()
+        a.mask_slope = mask_slope
     a.flags = flags
     if a.wp_format in (7, 8):
         want = torch.float16 if a.wp_format == 7 else torch.bfloat16
@@ -244,6 +257,13 @@ def _fill_conv_args(a, x: View, wp, bias, y: View, *, N, H, W, OH, OW, Cin, Cout
     a.slope = slope
     if mask is not None:
         a.mask, a.m_ldc, a.m_coff, a.mask_slope = mask.t.data_ptr(), mask.ldc, mask.coff, mask_slope
+
+
+def conv_signs_bytes(x: View, wp, bias, y: View, **kw) -> int:
+    """bytes of the sign-bit buffer the conv with these arguments writes / reads (0: its launch does not offer sign bits)"""
+    a = ConvArgs()
+    _fill_conv_args(a, x, wp, bias, y, **kw)
+    return int(lib().srk_conv3x3_signs_bytes(C.byref(a)))
 
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):

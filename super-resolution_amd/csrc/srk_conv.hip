@@ -1087,6 +1087,7 @@ int srk_launch_conv_wino42(const srk_conv_args& a, hipStream_t st);      // srk_
 int srk_conv_wino42_nmt(const srk_conv_args& a);
 int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st);         // srk_conv_h16.hip (wp_format 7 / 8)
 int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len);
+size_t srk_conv_h16_signs_bytes(const srk_conv_args& a);
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st);   // 1: launched as one chain kernel, 0: not eligible, < 0: error
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n);
 int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
@@ -1113,6 +1114,7 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
     if (px * ld * 4 > 0x7fffffffL) return SRK_ERR_UNSUPPORTED;
   }
   if (a.wp_format == 7 || a.wp_format == 8) return srk_launch_conv_h16(a, st);     // 16-bit activation storage: its own checks
+  if (a.flags & (SRK_CONV_WRITE_SIGNS | SRK_CONV_MASK_SIGNS)) return SRK_ERR_UNSUPPORTED;      // (sign bits: the 16-bit kernels only)
   if (a.wp_format == 1 || a.wp_format == 2) {
     if (!a.x || !a.y || !a.wp || a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return SRK_ERR_BAD_ARG;
     if (!srk_conv3x3_bf16x3_supported(pa) || (((uintptr_t)a.wp & 15) != 0)) return SRK_ERR_UNSUPPORTED;
@@ -1188,6 +1190,11 @@ extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
     if (rc) return rc;
   }
   return SRK_OK;
+}
+
+extern "C" size_t srk_conv3x3_signs_bytes(const srk_conv_args* pa) {
+  if (!pa || (pa->wp_format != 7 && pa->wp_format != 8)) return 0;
+  return srk_conv_h16_signs_bytes(*pa);
 }
 
 // Name of the ONE kernel srk_conv3x3_seq would launch for the whole sequence (the chain form), or "" when it launches the convolutions

@@ -94,11 +94,15 @@ template <int MT> struct HGeo {
 // ------------------------------------------------------------------------------------------------------------------ epilogue
 // acc[m][t][reg]: output row MT wv + m of the tile, pixel i = (reg & 3) + 8 (reg >> 2) + 4 hl of that row, channel n0 + 32 t + l32.
 // Item (m, j), j = 0..3: pixel pl = 8 j + (lane >> 3), channels n0 + 8 (lane & 7) .. + 7.  NS = how many of r1 / r2 / mask exist.
-// SAUX = cache-policy bits of the stores (0; the chain form writes through to device scope, see below).  BORDER: write through only what
-// another tile reads -- the outermost pixel ring of the MT*4 x 32 tile (18 % of it); the interior is re-read by this tile's own CU only.
-template <typename T, int MT, int NS, bool OUTF32, int SAUX = 0, bool BORDER = false>
-__device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][2], float* ls, int n, int oh0, int ow0, int n0, int wv, int lane) {
+// SAUX = cache-policy bits of the stores (16 = sc1, write-through: see H16_STORE_AUX above and the chain form below).
+template <typename T, int MT, int NS, bool OUTF32, int SAUX = 0>
+__device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][2], float* ls, int n, int oh0, int ow0, int n0, int wv, int lane, int tile) {
   typedef typename H16<T>::v8 v8;
+  // sign bits (srk_conv_args.signs): item (m, j) of the lane = bits 8 (4 m + j) .. + 7 of its 128; tile = the workgroup's index in the launch
+  h16_u32x4 sbits = {0u, 0u, 0u, 0u};
+  const bool wsigns = !OUTF32 && (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = !OUTF32 && (a.flags & SRK_CONV_MASK_SIGNS) != 0;
+  h16_u32x4* const sgp = reinterpret_cast<h16_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane;
+  if (msigns) sbits = *sgp;
   constexpr int TB = OUTF32 ? 1 : (NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1));    // M tiles per batch (loads ahead of stores)
   const int hl = lane >> 5, l32 = lane & 31;
   const int c8 = lane & 7, plb = lane >> 3;
@@ -228,6 +232,12 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
             for (int e = 0; e < 8; ++e) o[e] = rv[e] > 0.f ? o[e] : o[e] * sms[sidx];
           }
         }
+        if (msigns) {
+          const unsigned byte = sbits[(4 * m + j) >> 2] >> (8 * ((4 * m + j) & 3));
+          const float ms = srk_sgpr_opaque(a.mask_slope);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = ((byte >> e) & 1u) ? o[e] : o[e] * ms;
+        }
         const bool ok = (valid >> (4 * mm + j)) & 1;
         if constexpr (OUTF32) {
           // the fp32-output form (final conv of the generator, Cout = image channels): one dword per channel that exists
@@ -240,25 +250,20 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = o[e];
           const v8 hv = __builtin_convertvector(ov, v8);
-          const unsigned off = ok ? (unsigned)(pix[mm][j] * a.y_ldc + ch) * (unsigned)YB : H_OOB;
-          if constexpr (!BORDER) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
-          } else {
-            const int row = MT * wv + m;                           // (wave-uniform)
-            if (row == 0 || row == 4 * MT - 1) {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
-            } else if (j == 0 || j == 3) {                         // columns 0 (plb == 0 of j == 0) and 31 (plb == 7 of j == 3)
-              const bool edge = j == 0 ? plb == 0 : plb == 7;
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, edge ? off : H_OOB, 0, SAUX);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, edge ? H_OOB : off, 0, 0);
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, 0);
-            }
+          if (wsigns) {                                    // the sign of what is STORED (a value that rounds to zero counts as not positive)
+            const h16_f32x8 back = __builtin_convertvector(hv, h16_f32x8);
+            unsigned byte = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) byte |= (back[e] > 0.f ? 1u : 0u) << e;
+            sbits[(4 * m + j) >> 2] |= (ok ? byte : 0u) << (8 * ((4 * m + j) & 3));         // (no bits for pixels outside the image)
           }
+          const unsigned off = ok ? (unsigned)(pix[mm][j] * a.y_ldc + ch) * (unsigned)YB : H_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
         }
       }
     }
   }
+  if (wsigns) *sgp = sbits;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ kernel
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
     const int Tn = gridDim.x;                        // XCD-contiguous tile ranges: neighbouring tiles (shared halo rows) meet in one L2
     if ((Tn & 7) == 0) bid = (bid & 7) * (Tn >> 3) + (bid >> 3);
   }
+  const int tile = bid + (int)(gridDim.x * blockIdx.y);          // (index of the workgroup's sign bits)
   const int tx = bid % tilesW; bid /= tilesW;
   const int ty = bid % tilesH; bid /= tilesH;
   const int n = bid;
@@ -490,12 +496,12 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_kernel(const srk_c
   float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
   const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
   if constexpr (OUTF32) {
-    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
   } else {
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
   }
   H16_STAMP(4);
 #ifdef SRK_STAMP
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
     const int Tn = gridDim.x;
     if ((Tn & 7) == 0) bid = (bid & 7) * (Tn >> 3) + (bid >> 3);
   }
+  const int tile = bid + (int)(gridDim.x * blockIdx.y);          // (index of the workgroup's sign bits)
   const int tx = bid % tilesW; bid /= tilesW;
   const int ty = bid % tilesH; bid /= tilesH;
   const int n = bid;
@@ -681,12 +688,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16s_kernel(const srk_conv_arg
   float* ls = reinterpret_cast<float*>(smem) + wv * 2048;
   const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
   if constexpr (OUTF32) {
-    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    h16_epilogue<T, MT, 0, true>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
   } else {
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
-    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
+    else h16_epilogue<T, MT, 3, false, H16_STORE_AUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, tile);
   }
 }
 
@@ -720,9 +727,6 @@ typedef srk_chain_args h16_chain_args;
 #endif
 #ifndef H16_CHAIN_FRESH_DEV
 #define H16_CHAIN_FRESH_DEV 1
-#endif
-#ifndef H16_CHAIN_BORDER
-#define H16_CHAIN_BORDER 0       // 1: write through only the tile's outermost pixel ring (what other tiles read) -- measured 164 / 159 us instead of 135 / 142
 #endif
 #ifndef H16_CHAIN_SIG_STEP
 #define H16_CHAIN_SIG_STEP 12
@@ -950,10 +954,10 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     H16C_STAMP(0, c, 1);
     const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
-    if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
-    else h16_epilogue<T, MT, 3, false, STORE_AUX, H16_CHAIN_BORDER != 0>(a, acc, ls, n, oh0, ow0, 0, wv, lane);
+    if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
+    else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
+    else if (n_aux == 2) h16_epilogue<T, MT, 2, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
+    else h16_epilogue<T, MT, 3, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
     H16C_STAMP(0, c, 2);
     sig_pending = c + 1 < nconv;
   }
@@ -1071,6 +1075,11 @@ int srk_conv_h16_check(const srk_conv_args& a) {
   if (a.in_mode == SRK_IN_UNSHUFFLE && ((a.Cin & 3) || ((a.Cin >> 2) % 32))) return SRK_ERR_UNSUPPORTED;
   if ((a.x_ldc % 8) || (a.x_coff % 8) || (((uintptr_t)a.x | (uintptr_t)a.wp) & 15)) return SRK_ERR_ALIGNMENT;
   const bool f32o = a.flags & SRK_CONV_OUT_F32;
+  if (a.flags & (SRK_CONV_WRITE_SIGNS | SRK_CONV_MASK_SIGNS)) {        // sign bits (srk_conv_args.signs)
+    if ((a.flags & SRK_CONV_WRITE_SIGNS) && (a.flags & SRK_CONV_MASK_SIGNS)) return SRK_ERR_UNSUPPORTED;
+    if (f32o || a.ps_out || !a.signs || ((a.flags & SRK_CONV_MASK_SIGNS) && a.mask)) return SRK_ERR_UNSUPPORTED;
+    if (((uintptr_t)a.signs) & 15) return SRK_ERR_ALIGNMENT;
+  }
   if (f32o) {
     if (a.r1 || a.r2 || a.mask || a.ps_out) return SRK_ERR_UNSUPPORTED;
     if (((uintptr_t)a.y) & 3) return SRK_ERR_ALIGNMENT;
@@ -1147,6 +1156,16 @@ int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t 
   (void)n;
   snprintf(buf, len, "conv3x3_h16_chain_kernel<%s>", args[0].wp_format == 7 ? "_Float16" : "__bf16");
   return SRK_OK;
+}
+
+// bytes of the sign-bit buffer of this launch: 16 bytes per lane of its (grid.x x grid.y) four-wave workgroups; 0 = not supported
+size_t srk_conv_h16_signs_bytes(const srk_conv_args& a) {
+  srk_conv_args b = a;
+  b.flags &= ~(SRK_CONV_WRITE_SIGNS | SRK_CONV_MASK_SIGNS);
+  if ((b.flags & SRK_CONV_OUT_F32) || b.ps_out || srk_conv_h16_check(b) != SRK_OK) return 0;
+  const int mt = srk_conv_h16_mt(a);
+  const size_t tiles = (size_t)a.N * srk_div_up(a.OH, mt == 1 ? 8 : 4 * mt) * srk_div_up(a.OW, HW_TW) * (srk_round_up(a.Cout, 64) / 64);
+  return tiles * 4 * 64 * 16;
 }
 
 int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st) {

@@ -382,6 +382,8 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
+  // (sign bits -- srk_conv_args.signs, conv_epilogue's SIGNS -- are NOT offered by this kernel: with them the register allocation of the
+  // K loop changes, 4-68 spills depending on the instantiation; the 16-bit kernels have them)
   conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : W42_STORE_AUX>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);     // (16 = sc1: write-through)
   W42_STAMP(5);
   if constexpr (CHAIN) {

@@ -17,9 +17,12 @@ __device__ __forceinline__ const float* srk_sgpr_opaque(const float* p) {
 // "slots"), NBT = items per batch.  Straight-line code: every access is a buffer load / store through a per-image resource
 // whose out-of-range offsets (W_OOB: tile pixels outside the image, channels >= Cout) load 0 / store nothing, and the
 // slot roles are uniform coefficients instead of branches -- one basic block, so the compiler counts vmcnt exactly.
-template <int BN, int MT, bool ROWTILE, int NBT, int NS, int SAUX = 0>
+// SIGNS (kernels that support srk_conv_args.signs): tile = the workgroup's tile index; SRK_CONV_WRITE_SIGNS collects (o > 0) of the lane's
+// NI items x 4 channels (NI <= 32: 128 bits) and stores them with one 16-byte store; SRK_CONV_MASK_SIGNS takes the LeakyReLU' mask from
+// such bits (one 16-byte load) -- the mask is then NOT one of the NS tensors.
+template <int BN, int MT, bool ROWTILE, int NBT, int NS, int SAUX = 0, bool SIGNS = false>
 __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float* ls, int n, int oh0, int ow0,
-                                                  int n0, int wv, int lane, bool interior) {
+                                                  int n0, int wv, int lane, bool interior, int tile = 0) {
   constexpr int NTN = BN / 32, NG = NTN * MT, NI = NG * 4;
   constexpr int NB = NBT < NI ? NBT : NI;           // items per batch: whole accumulator tiles
   static_assert(NB % 4 == 0 && NI % NB == 0, "prefetch batch = whole accumulator tiles");
@@ -78,6 +81,17 @@ __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16
     srs[2] = rsrc_of(mkp, mkl, mkc);
     sld[2] = mkl; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
   }
+  typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
+  sg_u32x4 sbits = {0u, 0u, 0u, 0u};
+  bool wsigns = false, msigns = false;
+  float sg_slope = 1.f;
+  if constexpr (SIGNS) {
+    static_assert(NI <= 32, "128 sign bits per lane");
+    wsigns = (a.flags & SRK_CONV_WRITE_SIGNS) != 0;
+    msigns = (a.flags & SRK_CONV_MASK_SIGNS) != 0;
+    sg_slope = mask_slope;
+    if (msigns) sbits = *(reinterpret_cast<const sg_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane);
+  }
 #pragma unroll
   for (int b0 = 0; b0 < NI; b0 += NB) {
     int pix[NB];
@@ -126,6 +140,20 @@ __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16
       for (int sidx = 0; sidx < NS; ++sidx)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] *= (sv[sidx][k][e] > 0.f ? 1.f : sms[sidx]);
+      if constexpr (SIGNS) {
+        const int i = b0 + k;                       // item i: bits 4 i .. 4 i + 3 of the lane's 128
+        if (msigns) {
+          const unsigned nib = sbits[i >> 3] >> (4 * (i & 7));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= ((nib >> e) & 1u) ? 1.f : sg_slope;
+        }
+        if (wsigns) {
+          unsigned nib = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nib |= (o[e] > 0.f ? 1u : 0u) << e;
+          sbits[i >> 3] |= nib << (4 * (i & 7));
+        }
+      }
       const unsigned off = ((valid >> k) & 1) ? (unsigned)(pix[k] * a.y_ldc + ch[t]) * 4u : E_OOB;
 #ifdef SRK_NO_STORE
       asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(off));
@@ -134,15 +162,18 @@ __device__ __forceinline__ void conv_epilogue_vec(const srk_conv_args& a, f32x16
 #endif
     }
   }
+  if constexpr (SIGNS) {
+    if (wsigns) *(reinterpret_cast<sg_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane) = sbits;
+  }
 }
 
 // Fused epilogue shared by the conv kernels.  acc[m][t][reg]: pixel i = (reg&3) + 8*(reg>>2) + 4*hl of M tile m
 // (rows 2wv, 2wv+1 of the m-th 8-row group), channel = n0 + 32t + l32.
 // SAUX = cache-policy bits of the 16-byte stores (0; the chain kernels write through to device scope, srk_chain.h: their host side
 // admits only calls that take the 16-byte path).
-template <int BN, int MT, bool ROWTILE = false, int PF = 8, int PF2 = (PF > 4 ? PF / 2 : PF), int SAUX = 0>
+template <int BN, int MT, bool ROWTILE = false, int PF = 8, int PF2 = (PF > 4 ? PF / 2 : PF), int SAUX = 0, bool SIGNS = false>
 __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[MT][BN / 32], float4* smem, int n, int oh0,
-                                              int ow0, int n0, int wv, int lane, int lds_slot = -1) {
+                                              int ow0, int n0, int wv, int lane, int lds_slot = -1, int tile = 0) {
   constexpr int NTN = BN / 32;
   constexpr int TILE_H = ROWTILE ? 4 * MT : SRK_TH * MT;   // ROWTILE: a 32-pixel M tile is ONE image row (tile 4MT x 32)
   constexpr int TILE_W = ROWTILE ? 32 : SRK_TW;
@@ -179,10 +210,10 @@ __device__ __forceinline__ void conv_epilogue(const srk_conv_args& a, f32x16 (&a
     // Batch depth PF when at most one of r1 / r2 / mask is present (the usual case: dense-block convs carry a bias only,
     // data-gradient convs a mask only), PF2 with two of them, 4 with all three: the prefetched values stay within ~4 PF floats.
     const int n_aux = (has_r1 ? 1 : 0) + (has_r2 ? 1 : 0) + (has_m ? 1 : 0);
-    if (n_aux == 0) conv_epilogue_vec<BN, MT, ROWTILE, PF, 0, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else if (n_aux == 1) conv_epilogue_vec<BN, MT, ROWTILE, PF, 1, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else if (n_aux == 2) conv_epilogue_vec<BN, MT, ROWTILE, PF2, 2, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
-    else conv_epilogue_vec<BN, MT, ROWTILE, 4, 3, SAUX>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior);
+    if (n_aux == 0) conv_epilogue_vec<BN, MT, ROWTILE, PF, 0, SAUX, SIGNS>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior, tile);
+    else if (n_aux == 1) conv_epilogue_vec<BN, MT, ROWTILE, PF, 1, SAUX, SIGNS>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior, tile);
+    else if (n_aux == 2) conv_epilogue_vec<BN, MT, ROWTILE, PF2, 2, SAUX, SIGNS>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior, tile);
+    else conv_epilogue_vec<BN, MT, ROWTILE, 4, 3, SAUX, SIGNS>(a, acc, ls, n, oh0, ow0, n0, wv, lane, interior, tile);
   } else {
     // scalar path (Cout not a multiple of 4, e.g. the F->1 tail conv, or unaligned views): one dword per lane
     const int y_rs = rowmul * a.y_ldc, y_cs = colmul * a.y_ldc;

@@ -84,6 +84,10 @@ class GeneratorEngine:
         # "f32": exact-fp32 MFMA everywhere (default).  "bf16x3": forward / data-gradient convs whose K is a multiple
         # of 16 run as 3 split-bf16 MFMAs per product (fp32 accumulate, ~2^-16 operand precision); opt-in.
         self.precision = os.environ.get("SRK_PRECISION", "f32")
+        # 16-bit storage: LeakyReLU' masks of the data-gradient convolutions from sign bits the forward convolutions write (SRK_SIGN_BITS=0:
+        # from the forward activations themselves)
+        self.sign_bits = os.environ.get("SRK_SIGN_BITS", "1") != "0"
+        self._signs_bytes = {}
         self.use_graphs = os.environ.get("SRK_GRAPHS", "0") == "1"     # hipGraph replay of forward / backward (_GraphSet)
         self._graphs = {}
         self._side = None            # second HIP stream: weight-gradient kernels overlap the data-gradient chain
@@ -363,15 +367,29 @@ class GeneratorEngine:
         return _PackedW(self.flat_b.slices[i], 2 if (f == 1 and self.precision == "bf16") else f)
 
     # ------------------------------------------------------------------ building blocks
-    def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float):
+    def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float, save: bool = False):
         """One DenseResidualBlock on dense buffer D (slice 0 = block input).  ``outer_x`` is the RRDB input
-        for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53)."""
+        for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53).  ``save`` (16-bit storage): convs 1-4
+        also write the SIGN BITS of their outputs (srk_conv_args.signs: 1 MB instead of the 16.8 MB slice), which the block's
+        data-gradient convolutions take their LeakyReLU' masks from."""
         N, H, W = geo
         F_ = pk.F
         calls = []          # the block's five convolutions go to the library in ONE call (srk_conv3x3_seq)
+        signs = None
+        if save and self.precision in H16_DTYPE and self.sign_bits:
+            key = (N, H, W, F_, self.precision)
+            nb = self._signs_bytes.get(key)
+            if nb is None:
+                nb = self._signs_bytes[key] = L.conv_signs_bytes(View(D, 0, F_), self.wf(pk.fwd[1]), None, View(D, F_, F_), N=N, H=H, W=W,
+                                                               OH=H, OW=W, Cin=F_, Cout=F_, slope=G_SLOPE)
+            if nb > 0:
+                signs = torch.empty(4, nb, dtype=torch.uint8, device=D.device)
+        D._srk_signs = signs
         for k in range(1, 5):
-            calls.append((View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_),
-                          dict(N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)))
+            kw = dict(N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)
+            if signs is not None:
+                kw["signs_out"] = signs[k - 1]
+            calls.append((View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_), kw))
         b5 = d.b5[0].bias.data
         if outer_x is None:
             calls.append((View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
@@ -387,10 +405,15 @@ class GeneratorEngine:
         N, H, W = geo
         F_ = pk.F
         calls = []          # the five data-gradient convolutions in ONE library call
+        signs = getattr(D, "_srk_signs", None)        # written by the block's forward convolutions (16-bit storage)
         for m in range(4, 0, -1):
             K = (5 - m) * F_
-            calls.append((View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), dict(N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_,
-                          mask=View(D, m * F_, F_), mask_slope=G_SLOPE)))
+            kw = dict(N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_, mask_slope=G_SLOPE)
+            if signs is not None:
+                kw["mask_signs"] = signs[m - 1]
+            else:
+                kw["mask"] = View(D, m * F_, F_)
+            calls.append((View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), kw))
         calls.append((View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
                       r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)))
         L.conv3x3_seq(calls)
@@ -446,7 +469,7 @@ class GeneratorEngine:
                 else:
                     nxt = _empty(N, H, W, 5 * F_, device=dev, dtype=self.act_dtype)
                     out = View(nxt, 0, F_)
-                self._drb_forward(d, packs[i][j], cur, out, geo, View(first, 0, F_) if j == 2 else None, rr.res_scale)
+                self._drb_forward(d, packs[i][j], cur, out, geo, View(first, 0, F_) if j == 2 else None, rr.res_scale, save)
                 if not last:
                     bufs.append(nxt)
                 cur = nxt

@@ -256,6 +256,74 @@ def test_h16_wgrad_dense_block_batch_unshuffle_and_padded_channels(U, fmt):
 
 
 # ------------------------------------------------------------------------------------------------------------ whole generator
+@pytest.mark.parametrize("fmt", [7, 8])
+@pytest.mark.parametrize("mt", [1, 2, 4])
+def test_h16_sign_bits_equal_the_mask_tensor(U, fmt, mt):
+    """srk_conv_args.signs: a forward conv writes the sign bits of what it stores (1 MB per dense-block conv instead of the 16.8 MB
+    slice); a data-gradient conv that takes its LeakyReLU' mask from them gives the SAME bits as with the mask tensor -- on ragged
+    multi-tile images, every tile form, values that round to zero included."""
+    L = U.L
+    L.lib().srk_debug_set_h16_mt(mt)
+    n, h, w, F_ = 2, 37, 70, 64
+    x = _rand((n, 2 * F_, h, w), 90)
+    x[:, :, ::5, ::7] = 0                                     # exact zeros in the input: outputs that are exactly / nearly zero
+    wt = _rand((F_, 2 * F_, 3, 3), 91, 0.03)
+    b = _rand((F_,), 92, 0.05)
+    xb = _nhwc16(U, x, fmt)
+    y = torch.zeros(n, h, w, F_, device="cuda", dtype=DT[fmt])
+    kw = dict(N=n, H=h, W=w, OH=h, OW=w, Cin=2 * F_, Cout=F_, slope=0.2)
+    nb = L.conv_signs_bytes(L.View(xb), _pack(U, wt, fmt), b.cuda(), L.View(y), **kw)
+    assert nb > 0 and nb % 16 == 0
+    signs = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    wp = _pack(U, wt, fmt)
+    L.conv3x3(L.View(xb), wp, b.cuda(), L.View(y), signs_out=signs, **kw)
+    y_plain = torch.zeros_like(y)
+    L.conv3x3(L.View(xb), wp, b.cuda(), L.View(y_plain), **kw)
+    assert torch.equal(y, y_plain)                            # writing the bits changes nothing else
+    # total number of set bits = number of positive stored values (the layout is private; the count is not)
+    bits = torch.from_numpy(__import__("numpy").unpackbits(signs.cpu().numpy())).sum().item()
+    assert bits == int((y.float() > 0).sum().item())
+    # the data gradient of a following conv, masked by y: from the tensor and from the bits
+    g = _q(_rand((n, F_, h, w), 93), fmt)
+    w2 = _rand((F_, F_, 3, 3), 94, 0.05)
+    wpb = _pack(U, w2, fmt, transpose=True)
+    gb = _nhwc16(U, g, fmt)
+    kw2 = dict(N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_, mask_slope=0.2)
+    d_ref = torch.zeros(n, h, w, F_, device="cuda", dtype=DT[fmt])
+    L.conv3x3(L.View(gb), wpb, None, L.View(d_ref), mask=L.View(y), **kw2)
+    d_bits = torch.zeros_like(d_ref)
+    L.conv3x3(L.View(gb), wpb, None, L.View(d_bits), mask_signs=signs, **kw2)
+    assert torch.equal(d_bits, d_ref)
+    assert (d_ref.float().abs() > 0).float().mean().item() > 0.5
+
+
+def test_h16_sign_bits_contract(U):
+    L = U.L
+    n, h, w, F_ = 1, 16, 32, 64
+    xb = _nhwc16(U, _rand((n, F_, h, w), 95), 7)
+    wp = _pack(U, _rand((F_, F_, 3, 3), 96, 0.05), 7)
+    y = torch.zeros(n, h, w, F_, device="cuda", dtype=torch.float16)
+    kw = dict(N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=F_)
+    signs = torch.zeros(L.conv_signs_bytes(L.View(xb), wp, None, L.View(y), **kw), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):          # both a mask tensor and mask bits
+        L.conv3x3(L.View(xb), wp, None, L.View(y), mask=L.View(y), mask_signs=signs, **kw)
+    with pytest.raises(RuntimeError):          # the fp32-output form has no sign bits
+        L.conv3x3(L.View(xb), wp, None, L.View(torch.zeros(n, h, w, F_, device="cuda")), signs_out=signs, flags=L.CONV_OUT_F32, **kw)
+    # the fp32 kernels do not offer them
+    x32 = U.nhwc(_rand((n, F_, h, w), 97)).cuda()
+    w32 = U.pack_fwd(_rand((F_, F_, 3, 3), 98, 0.05), fmt=6)[0]
+
+    class PW6:
+        fmt = 6
+
+        def data_ptr(self):
+            return w32.data_ptr()
+    y32 = torch.zeros(n, h, w, F_, device="cuda")
+    assert L.conv_signs_bytes(L.View(x32), PW6(), None, L.View(y32), **kw) == 0
+    with pytest.raises(RuntimeError):
+        L.conv3x3(L.View(x32), PW6(), None, L.View(y32), signs_out=signs, **kw)
+
+
 # ---------------------------------------------------------------------------------------------- the chain form (one launch per dense block)
 def _dense_block_calls(U, fmt, n, h, w, backward, seed):
     """the engine's two sequences (engine.py _drb_forward / _drb_backward) on random data: conv k reads slices 0..k-1 of D and writes
@@ -324,6 +392,44 @@ def test_h16_chain_matches_separate_launches(U, fmt, backward, n, h, w):
             first = (D.clone(), out.clone())
         else:
             assert torch.equal(D, first[0]) and torch.equal(out, first[1])
+
+
+def test_h16_chain_writes_and_reads_the_same_sign_bits_as_separate_launches(U):
+    """forward sequence with sign bits through the chain form and conv by conv: same bits; data-gradient sequence masked by them: the
+    chain's results within the usual last place of the separate launches'"""
+    L = U.L
+    n, h, w = 8, 128, 128
+    D, out, calls, keep = _dense_block_calls(U, 7, n, h, w, False, 600)
+    nb = L.conv_signs_bytes(calls[0][0], calls[0][1], calls[0][2], calls[0][3], **calls[0][4])
+    sg = [torch.zeros(4, nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for mode, s_ in ((0, sg[0]), (1, sg[1])):
+        L.lib().srk_debug_set_h16_chain(mode)
+        D[..., 64:] = 0
+        cs = [(x, wp, b, y, dict(kw, signs_out=s_[k]) if k < 4 else kw) for k, (x, wp, b, y, kw) in enumerate(calls)]
+        assert (_seq_kernel(L, cs) != "") == (mode == 1)
+        L.conv3x3_seq(cs)
+        torch.cuda.synchronize()
+    # the two forward paths differ in the last place of a few outputs (order of the fp32 sums): so may a few sign bits of values next to zero
+    diff = (sg[0] != sg[1]).float().mean().item()
+    assert diff < 1e-3
+    Db, outb, callsb, keepb = _dense_block_calls(U, 7, n, h, w, True, 601)
+    res = []
+    for mode in (0, 1):
+        L.lib().srk_debug_set_h16_chain(mode)
+        Db[..., 64:] = 0
+        outb.zero_()
+        cs = []
+        for k, (x, wp, b, y, kw) in enumerate(callsb):
+            kw = dict(kw)
+            if k < 4:
+                kw.pop("mask")
+                kw["mask_signs"] = sg[1][k]
+            cs.append((x, wp, b, y, kw))
+        L.conv3x3_seq(cs)
+        torch.cuda.synchronize()
+        res.append((Db.float().clone(), outb.float().clone()))
+    tol = 6 * TOL16[7] * res[0][0].abs().max().item()
+    assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol
 
 
 def test_h16_chain_eligibility(U):
