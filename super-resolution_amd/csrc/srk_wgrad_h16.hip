@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
     const int b = (tile - t_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifndef WH_NO_DMA       // (-DWH_NO_DMA / -DWH_NO_MFMA: timing-only ablation builds for tools/debug/wgrad_h16_ablate.py -- wrong results)
     if (tile + 1 < t_end) stage(tile + 1, b ^ 1);
+#endif
     const char* buf = reinterpret_cast<const char*>(smem + b * HT_STAGE4);
     if (active) {
       // Fragments are read AHEAD by hand (sched_barrier between the slots): left to the compiler every x fragment was read right in
@@ -202,7 +204,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const int kk = ri - r;
+#ifndef WH_NO_MFMA
           if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & 3], acc[3 * r + s]);
+#else
+          if (kk >= 0 && kk < HT_H) { acc[3 * r + s][0] += (float)af[kk][0] + (float)bring[i & 3][0]; }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
