@@ -53,13 +53,17 @@ __device__ __forceinline__ typename WH<T>::v4 wh_tr_read(const char* p) {
   return __builtin_bit_cast(typename WH<T>::v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wh_s16x4*)p));
 }
 
-template <typename T, int DYMODE>
-__global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float* part, float* pbias) {
+// LD (loader form): ONE workgroup per CU = four MFMA waves (one per SIMD) + four loader waves.  The ablation of the two-workgroups form
+// (tools/debug/wgrad_h16_ablate.py) shows MFMAs, DMA issue and fragment reads overlapping only partly in waves that do all three; here
+// the MFMA waves issue no vector-memory instruction, the loaders keep TWO tiles in flight (three stage buffers), one barrier per tile.
+template <typename T, int DYMODE, bool LD>
+__global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBatch B, float* part, float* pbias) {
   typedef typename WH<T>::v8 v8;
   typedef typename WH<T>::v4 v4;
-  __shared__ float4 smem[2 * HT_STAGE4];
+  __shared__ float4 smem[(LD ? 3 : 2) * HT_STAGE4];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = wv8 & 3;                 // MFMA wave (a, b) resp. the piece owner among the four waves that issue the DMA
   // XCD-aware id -> (pixel split p, chunk): all chunks of a split read the same x / dy tiles and must meet in ONE L2
   int p, chunk;
   {
@@ -158,13 +162,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
   const int a_lane = (wa * HT_P + 8 * h + q) * 64 + lane_col;                          // + (16 kk + 4 rd) * 64
   const int b_lane = HT_XBASE * 16 + (wb * HT_NHP + 8 * h + q) * 64 + lane_col;        // + (ri * IW + 4 rd + s) * 64
 
-  if (t_begin < t_end) stage(t_begin, 0);
+  if constexpr (LD) {
+    if (wv8 >= 4) {
+      // ---- loader waves: pieces per tile and wave 4 dy + 6 x (wave 3: 5 x); tiles it + 1, it + 2 in flight while tile it is computed
+      if (t_begin < t_end) stage(t_begin, 0);
+      if (t_begin + 1 < t_end) stage(t_begin + 1, 1);
+      for (int tile = t_begin; tile < t_end; ++tile) {
+        // (vector-memory operations retire in order: all but the pieces of the NEXT tile = this tile has landed)
+        if (tile + 1 < t_end) { if (wv == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... and the MFMA waves are done with tile - 1, whose buffer tile + 2 goes to
+        if (tile + 2 < t_end) stage(tile + 2, (tile + 2 - t_begin) % 3);
+      }
+      return;
+    }
+  }
+  if (!LD && t_begin < t_end) stage(t_begin, 0);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int b = (tile - t_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int b = LD ? (tile - t_begin) % 3 : (tile - t_begin) & 1;
+    if (!LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (my fragment reads of the previous tile have returned)
     __builtin_amdgcn_s_barrier();
 #ifndef WH_NO_DMA       // (-DWH_NO_DMA / -DWH_NO_MFMA: timing-only ablation builds for tools/debug/wgrad_h16_ablate.py -- wrong results)
-    if (tile + 1 < t_end) stage(tile + 1, b ^ 1);
+    if (!LD && tile + 1 < t_end) stage(tile + 1, b ^ 1);
 #endif
     const char* buf = reinterpret_cast<const char*>(smem + b * HT_STAGE4);
     if (active) {
@@ -180,16 +200,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
         for (int j = 0; j < 4; ++j) { bf[j] = h0[j]; bf[4 + j] = h1[j]; }
         return bf;
       };
-      constexpr int NSTEP = 3 * (HT_H + 2), AHEAD = 3;
-      v8 bring[4];
-#pragma unroll
-      for (int kk = 0; kk < HT_H; ++kk) {
+      // (LD: one MFMA wave per SIMD -- nothing else covers the LDS latency: five steps ahead in a ring of eight, and the first x fragments
+      // in front of all but the first two dy fragments, so that the first MFMAs wait for four reads, not for twenty-two)
+      constexpr int NSTEP = 3 * (HT_H + 2), AHEAD = LD ? 5 : 3, RING = LD ? 8 : 4;
+      v8 bring[RING];
+      auto rdA = [&](int kk) {
         const v4 h0 = wh_tr_read<T>(buf + a_lane + (16 * kk) * 64), h1 = wh_tr_read<T>(buf + a_lane + (16 * kk + 4) * 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { af[kk][j] = h0[j]; af[kk][4 + j] = h1[j]; }
-      }
+      };
+      if constexpr (LD) {
+        rdA(0); rdA(1);
 #pragma unroll
-      for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
+        for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
+#pragma unroll
+        for (int kk = 2; kk < HT_H; ++kk) rdA(kk);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < HT_H; ++kk) rdA(kk);
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (do_bias) {
 #pragma unroll
@@ -199,15 +230,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
 #pragma unroll
       for (int i = 0; i < NSTEP; ++i) {
         const int s = i / (HT_H + 2), ri = i % (HT_H + 2);
-        if (i + AHEAD < NSTEP) bring[(i + AHEAD) & 3] = rdB(i + AHEAD);
+        if (i + AHEAD < NSTEP) bring[(i + AHEAD) & (RING - 1)] = rdB(i + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const int kk = ri - r;
 #ifndef WH_NO_MFMA
-          if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & 3], acc[3 * r + s]);
+          if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & (RING - 1)], acc[3 * r + s]);
 #else
-          if (kk >= 0 && kk < HT_H) { acc[3 * r + s][0] += (float)af[kk][0] + (float)bring[i & 3][0]; }
+          if (kk >= 0 && kk < HT_H) { acc[3 * r + s][0] += (float)af[kk][0] + (float)bring[i & (RING - 1)][0]; }
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -239,12 +270,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_h16_kernel(const WBatch B, float
 
 int srk_launch_wgrad_h16(const WBatch& B, int precision, float* part, float* pbias, hipStream_t st) {
   dim3 grid((unsigned)(B.P * B.n_chunks));
-  if (precision == 3) {
-    if (B.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_UNSHUFFLE>), grid, dim3(256), 0, st, B, part, pbias);
-    else hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_PLAIN>), grid, dim3(256), 0, st, B, part, pbias);
+  const bool un = B.dy_mode == SRK_IN_UNSHUFFLE;
+  if (B.h16 == 2) {          // the loader form: one workgroup per CU (srk_wgrad.hip plans half as many pixel splits for it)
+    if (precision == 3) {
+      if (un) hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_UNSHUFFLE, true>), grid, dim3(512), 0, st, B, part, pbias);
+      else hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_PLAIN, true>), grid, dim3(512), 0, st, B, part, pbias);
+    } else {
+      if (un) hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_UNSHUFFLE, true>), grid, dim3(512), 0, st, B, part, pbias);
+      else hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_PLAIN, true>), grid, dim3(512), 0, st, B, part, pbias);
+    }
+  } else if (precision == 3) {
+    if (un) hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_UNSHUFFLE, false>), grid, dim3(256), 0, st, B, part, pbias);
+    else hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_PLAIN, false>), grid, dim3(256), 0, st, B, part, pbias);
   } else {
-    if (B.dy_mode == SRK_IN_UNSHUFFLE) hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_UNSHUFFLE>), grid, dim3(256), 0, st, B, part, pbias);
-    else hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_PLAIN>), grid, dim3(256), 0, st, B, part, pbias);
+    if (un) hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_UNSHUFFLE, false>), grid, dim3(256), 0, st, B, part, pbias);
+    else hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_PLAIN, false>), grid, dim3(256), 0, st, B, part, pbias);
   }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
