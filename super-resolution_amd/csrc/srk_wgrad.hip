@@ -996,7 +996,7 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   // two-workgroups-per-CU form everywhere
   static int h16_form = -1;
   if (h16_form < 0) { const char* e = getenv("SRK_WGRAD_H16_FORM"); h16_form = e ? atoi(e) : 1; }
-  if (h16 && h16_form == 1 && B.total_tiles >= 8 * (h16_target / 2 / nc > 0 ? h16_target / 2 / nc : 1)) { B.h16 = 2; target = h16_target / 2 / nc; }
+  if (h16 && h16_form >= 1 && B.total_tiles >= 8 * (h16_target / 2 / nc > 0 ? h16_target / 2 / nc : 1)) { B.h16 = 2; target = h16_target / 2 / nc; }
   if (nc == 1 && args[0].Cin <= 32) target = tiny_target;
   if (target < 1) target = 1;
   // every pixel-split costs a 147 KB partial block per chunk (written, then read by the reduction): do not

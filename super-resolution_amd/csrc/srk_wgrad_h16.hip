@@ -34,13 +34,16 @@ template <> struct WH<__bf16> {
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int HT_H = W16_TH, HT_P = HT_H * WTW, HT_IW = WTW + 2, HT_NHP = (HT_H + 2) * HT_IW;     // 128 px, 180 halo px
-constexpr int HT_DY_SLOTS = 2 * HT_P * 4;                 // [half][128 px][4 x 8 ch]: 1024 16-byte slots = 16 pieces
-constexpr int HT_X_SLOTS = 2 * HT_NHP * 4;                // [half][180 px][4 x 8 ch]: 1440 slots = 22.5 pieces
-constexpr int HT_DY_PIECES = HT_DY_SLOTS / 64, HT_X_PIECES = (HT_X_SLOTS + 63) / 64;
-constexpr int HT_STAGE4 = (HT_DY_PIECES + HT_X_PIECES) * 64;      // 2496 slots = 39,936 B per stage
-constexpr int HT_XBASE = HT_DY_PIECES * 64;
-constexpr int HT_NJD = HT_DY_PIECES / 4, HT_NJX = (HT_X_PIECES + 3) / 4;
+// tile geometry by its height TH (8: both forms; 16: the loader form on launches with enough tiles)
+template <int TH> struct WHG {
+  static constexpr int H = TH, P = TH * WTW, IW = WTW + 2, NHP = (TH + 2) * IW;        // 128 / 256 px, 180 / 324 halo px
+  static constexpr int DY_SLOTS = 2 * P * 4;                 // [half][px][4 x 8 ch] 16-byte slots
+  static constexpr int X_SLOTS = 2 * NHP * 4;
+  static constexpr int DY_PIECES = DY_SLOTS / 64, X_PIECES = (X_SLOTS + 63) / 64;      // 16 + 22.5 / 32 + 40.5 one-KB pieces
+  static constexpr int STAGE4 = (DY_PIECES + X_PIECES) * 64;                           // 39,936 / 74,752 B per stage
+  static constexpr int XBASE = DY_PIECES * 64;
+  static constexpr int NJD = DY_PIECES / 4, NJX = (X_PIECES + 3) / 4;
+};
 constexpr unsigned HT_OOB = 0x80000000u;
 
 // (a plain function: from inside the kernel template the host pass of hipcc 7.2 silently dropped the kernel's host stub)
@@ -56,11 +59,13 @@ __device__ __forceinline__ typename WH<T>::v4 wh_tr_read(const char* p) {
 // LD (loader form): ONE workgroup per CU = four MFMA waves (one per SIMD) + four loader waves.  The ablation of the two-workgroups form
 // (tools/debug/wgrad_h16_ablate.py) shows MFMAs, DMA issue and fragment reads overlapping only partly in waves that do all three; here
 // the MFMA waves issue no vector-memory instruction, the loaders keep TWO tiles in flight (three stage buffers), one barrier per tile.
-template <typename T, int DYMODE, bool LD>
+template <typename T, int DYMODE, bool LD, int TH>
 __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBatch B, float* part, float* pbias) {
   typedef typename WH<T>::v8 v8;
   typedef typename WH<T>::v4 v4;
-  __shared__ float4 smem[(LD ? 3 : 2) * HT_STAGE4];
+  typedef WHG<TH> G;
+  constexpr int NSTAGE = (LD && TH == 8) ? 3 : 2;          // stage buffers (160 KB of LDS: three 8-row stages or two 16-row ones)
+  __shared__ float4 smem[NSTAGE * G::STAGE4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = wv8 & 3;                 // MFMA wave (a, b) resp. the piece owner among the four waves that issue the DMA
@@ -84,12 +89,12 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
 
   // ---- DMA plan.  Slot = (half * NPX + px) * 4 + g: 8 channels [32 half + 8 g, +8) of pixel px.  Piece i = slots 64 i .. 64 i + 63.
   // per lane and piece: pixel coordinates relative to the tile and the channel offset; the rest is per tile
-  int d_py[HT_NJD], d_px[HT_NJD], d_ch[HT_NJD];        // dy pieces of this wave: wv + 4 j
-  int x_py[HT_NJX], x_px[HT_NJX], x_ch[HT_NJX];
+  int d_py[G::NJD], d_px[G::NJD], d_ch[G::NJD];        // dy pieces of this wave: wv + 4 j
+  int x_py[G::NJX], x_px[G::NJX], x_ch[G::NJX];
 #pragma unroll
-  for (int j = 0; j < HT_NJD; ++j) {
+  for (int j = 0; j < G::NJD; ++j) {
     const int slot = (wv + 4 * j) * 64 + lane;
-    const int g = slot & 3, px = (slot >> 2) % HT_P, half = (slot >> 2) / HT_P;
+    const int g = slot & 3, px = (slot >> 2) % G::P, half = (slot >> 2) / G::P;
     d_py[j] = px / WTW; d_px[j] = px % WTW;
     const int co = cout0 + 32 * half + 8 * g;
     int ch = co;
@@ -97,12 +102,12 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
     d_ch[j] = co < CoutP ? ch : -1;
   }
 #pragma unroll
-  for (int j = 0; j < HT_NJX; ++j) {
+  for (int j = 0; j < G::NJX; ++j) {
     const int slot = (wv + 4 * j) * 64 + lane;
-    const int g = slot & 3, hp = (slot >> 2) % HT_NHP, half = (slot >> 2) / HT_NHP;
-    x_py[j] = hp / HT_IW; x_px[j] = hp % HT_IW;
+    const int g = slot & 3, hp = (slot >> 2) % G::NHP, half = (slot >> 2) / G::NHP;
+    x_py[j] = hp / G::IW; x_px[j] = hp % G::IW;
     const int ci = cin0 + 32 * half + 8 * g;
-    x_ch[j] = (slot < HT_X_SLOTS && ci < CinP) ? ci : -1;
+    x_ch[j] = (slot < G::X_SLOTS && ci < CinP) ? ci : -1;
   }
   const long x_img = (long)B.H * B.W * a.x_ldc;
   const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
@@ -111,12 +116,12 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
     const int tx = tt % B.tilesW; tt /= B.tilesW;
     const int ty = tt % B.tilesH; tt /= B.tilesH;
     const int n = tt;
-    const int oh0 = ty * HT_H, ow0 = tx * WTW;
+    const int oh0 = ty * G::H, ow0 = tx * WTW;
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dyb + (long)n * dy_img), 0, (unsigned)(dy_img * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb + (long)n * x_img), 0, (unsigned)(x_img * 2), 0x00020000);
-    float4* dst = smem + b * HT_STAGE4;
+    float4* dst = smem + b * G::STAGE4;
 #pragma unroll
-    for (int j = 0; j < HT_NJD; ++j) {
+    for (int j = 0; j < G::NJD; ++j) {
       const int oh = oh0 + d_py[j], ow = ow0 + d_px[j];
       unsigned vo = HT_OOB;
       if (d_ch[j] >= 0 && oh < B.OH && ow < B.OW) {
@@ -130,12 +135,12 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
       wh_dma(drs, dst + (wv + 4 * j) * 64, vo);
     }
 #pragma unroll
-    for (int j = 0; j < HT_NJX; ++j) {
-      if (wv + 4 * j < HT_X_PIECES) {
+    for (int j = 0; j < G::NJX; ++j) {
+      if (wv + 4 * j < G::X_PIECES) {
         const int ih = oh0 - 1 + x_py[j], iw = ow0 - 1 + x_px[j];
         unsigned vo = HT_OOB;
         if (x_ch[j] >= 0 && ih >= 0 && iw >= 0 && ih < B.H && iw < B.W) vo = (unsigned)(((ih * B.W + iw) * a.x_ldc + a.x_coff + x_ch[j]) * 2);
-        wh_dma(xrs, dst + HT_XBASE + (wv + 4 * j) * 64, vo);
+        wh_dma(xrs, dst + G::XBASE + (wv + 4 * j) * 64, vo);
       }
     }
   };
@@ -159,89 +164,117 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
   // the group supplies row q, channels 4 pp .. 4 pp + 3 and RECEIVES channel (lane & 15) of the group's 16, i.e. channel lane & 31.
   const int g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, pp = lane & 3;
   const int lane_col = (16 * (g & 1) + 4 * pp) * 2;
-  const int a_lane = (wa * HT_P + 8 * h + q) * 64 + lane_col;                          // + (16 kk + 4 rd) * 64
-  const int b_lane = HT_XBASE * 16 + (wb * HT_NHP + 8 * h + q) * 64 + lane_col;        // + (ri * IW + 4 rd + s) * 64
+  const int a_lane = (wa * G::P + 8 * h + q) * 64 + lane_col;                          // + (16 kk + 4 rd) * 64
+  const int b_lane = G::XBASE * 16 + (wb * G::NHP + 8 * h + q) * 64 + lane_col;        // + (ri * IW + 4 rd + s) * 64
 
   if constexpr (LD) {
     if (wv8 >= 4) {
-      // ---- loader waves: pieces per tile and wave 4 dy + 6 x (wave 3: 5 x); tiles it + 1, it + 2 in flight while tile it is computed
-      if (t_begin < t_end) stage(t_begin, 0);
-      if (t_begin + 1 < t_end) stage(t_begin + 1, 1);
+      // ---- loader waves: NSTAGE - 1 tiles in flight beside the one being computed.  Vector-memory operations retire in order: with at
+      // most the pieces of the tiles issued AFTER this one outstanding, this one has landed (pieces per tile: NJD dy + NJX x, the
+      // higher waves one x piece fewer when X_PIECES is not a multiple of four)
+      constexpr int DEPTH = NSTAGE - 1;
+      const int npc = G::NJD + G::NJX - ((wv + 4 * (G::NJX - 1) < G::X_PIECES) ? 0 : 1);       // my pieces per tile (wave-uniform)
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) if (t_begin + d < t_end) stage(t_begin + d, d);
       for (int tile = t_begin; tile < t_end; ++tile) {
-        // (vector-memory operations retire in order: all but the pieces of the NEXT tile = this tile has landed)
-        if (tile + 1 < t_end) { if (wv == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();              // ... and the MFMA waves are done with tile - 1, whose buffer tile + 2 goes to
-        if (tile + 2 < t_end) stage(tile + 2, (tile + 2 - t_begin) % 3);
+        if (DEPTH == 2 && tile + 1 < t_end) {
+          if (npc == G::NJD + G::NJX) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NJD + G::NJX) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NJD + G::NJX - 1) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();              // ... and the MFMA waves are done with tile - 1, whose buffer tile + DEPTH goes to
+        if (tile + DEPTH < t_end) stage(tile + DEPTH, (tile + DEPTH - t_begin) % NSTAGE);
       }
       return;
     }
   }
   if (!LD && t_begin < t_end) stage(t_begin, 0);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int b = LD ? (tile - t_begin) % 3 : (tile - t_begin) & 1;
+    const int b = LD ? (tile - t_begin) % NSTAGE : (tile - t_begin) & 1;
     if (!LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (my fragment reads of the previous tile have returned)
     __builtin_amdgcn_s_barrier();
 #ifndef WH_NO_DMA       // (-DWH_NO_DMA / -DWH_NO_MFMA: timing-only ablation builds for tools/debug/wgrad_h16_ablate.py -- wrong results)
     if (!LD && tile + 1 < t_end) stage(tile + 1, b ^ 1);
 #endif
-    const char* buf = reinterpret_cast<const char*>(smem + b * HT_STAGE4);
+    const char* buf = reinterpret_cast<const char*>(smem + b * G::STAGE4);
     if (active) {
-      // Fragments are read AHEAD by hand (sched_barrier between the slots): left to the compiler every x fragment was read right in
-      // front of the MFMAs that use it (read, wait, 1-3 MFMAs: the LDS latency of 30 fragments per tile on top of 80 MFMAs).
-      v8 af[HT_H];
-      auto rdB = [&](int i) {                      // x fragment of step i = HT_IW-row ri, column shift s (i = s * (HT_H + 2) + ri)
-        const int s = i / (HT_H + 2), ri = i % (HT_H + 2);
-        const char* base = buf + b_lane + (ri * HT_IW + s) * 64;
+      auto rdX = [&](int ri, int s) {              // x fragment: halo row ri, column shift s
+        const char* base = buf + b_lane + (ri * G::IW + s) * 64;
         const v4 h0 = wh_tr_read<T>(base), h1 = wh_tr_read<T>(base + 4 * 64);
         v8 bf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { bf[j] = h0[j]; bf[4 + j] = h1[j]; }
         return bf;
       };
-      // (LD: one MFMA wave per SIMD -- nothing else covers the LDS latency: five steps ahead in a ring of eight, and the first x fragments
-      // in front of all but the first two dy fragments, so that the first MFMAs wait for four reads, not for twenty-two)
-      constexpr int NSTEP = 3 * (HT_H + 2), AHEAD = LD ? 5 : 3, RING = LD ? 8 : 4;
-      v8 bring[RING];
-      auto rdA = [&](int kk) {
+      auto rdY = [&](int kk) {                     // dy fragment: tile row kk
         const v4 h0 = wh_tr_read<T>(buf + a_lane + (16 * kk) * 64), h1 = wh_tr_read<T>(buf + a_lane + (16 * kk + 4) * 64);
+        v8 f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { af[kk][j] = h0[j]; af[kk][4 + j] = h1[j]; }
+        for (int j = 0; j < 4; ++j) { f[j] = h0[j]; f[4 + j] = h1[j]; }
+        return f;
       };
+      // Fragments are read AHEAD by hand (sched_barrier between the slots): left to the compiler every x fragment was read right in
+      // front of the MFMAs that use it (read, wait, 1-3 MFMAs: the LDS latency of 30 fragments per tile on top of 80 MFMAs).
       if constexpr (LD) {
-        rdA(0); rdA(1);
+        // Halo row ri OUTER, column shift s inner: x fragment (ri, s) meets the dy rows kk = ri - r (r = 0..2), so only FOUR dy fragments
+        // are live (rows ri + 1 .. ri - 2: a ring) instead of all TH, and they stream in one row ahead instead of in a burst at the
+        // head of the tile.  One MFMA wave per SIMD: nothing else covers the LDS latency -- x fragments five steps ahead (ring of eight).
+        constexpr int NR = G::H + 2, NSTEP = 3 * NR, AHEAD = 5, RING = 8;
+        v8 ay[4], bx[RING];
+        ay[0] = rdY(0);
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
-#pragma unroll
-        for (int kk = 2; kk < HT_H; ++kk) rdA(kk);
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < HT_H; ++kk) rdA(kk);
-#pragma unroll
-        for (int i = 0; i < AHEAD; ++i) bring[i] = rdB(i);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (do_bias) {
-#pragma unroll
-        for (int kk = 0; kk < HT_H; ++kk) accb = WH<T>::mfma(af[kk], ones, accb);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NSTEP; ++i) {
-        const int s = i / (HT_H + 2), ri = i % (HT_H + 2);
-        if (i + AHEAD < NSTEP) bring[(i + AHEAD) & (RING - 1)] = rdB(i + AHEAD);
+        for (int j = 0; j < AHEAD; ++j) bx[j] = rdX(j / 3, j % 3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int kk = ri - r;
+        for (int j = 0; j < NSTEP; ++j) {
+          const int ri = j / 3, s = j % 3;
+          if (j + AHEAD < NSTEP) bx[(j + AHEAD) & (RING - 1)] = rdX((j + AHEAD) / 3, (j + AHEAD) % 3);
+          if (s == 0 && ri + 1 < G::H) ay[(ri + 1) & 3] = rdY(ri + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s == 0 && ri < G::H) { if (do_bias) accb = WH<T>::mfma(ay[ri & 3], ones, accb); }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int kk = ri - r;
 #ifndef WH_NO_MFMA
-          if (kk >= 0 && kk < HT_H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & (RING - 1)], acc[3 * r + s]);
+            if (kk >= 0 && kk < G::H) acc[3 * r + s] = WH<T>::mfma(ay[kk & 3], bx[j & (RING - 1)], acc[3 * r + s]);
 #else
-          if (kk >= 0 && kk < HT_H) { acc[3 * r + s][0] += (float)af[kk][0] + (float)bring[i & (RING - 1)][0]; }
+            if (kk >= 0 && kk < G::H) { acc[3 * r + s][0] += (float)ay[kk & 3][0] + (float)bx[j & (RING - 1)][0]; }
 #endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        v8 af[G::H];
+        constexpr int NSTEP = 3 * (G::H + 2), AHEAD = 3;      // step i = s * (H + 2) + ri
+        v8 bring[4];
+#pragma unroll
+        for (int kk = 0; kk < G::H; ++kk) af[kk] = rdY(kk);
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) bring[i] = rdX(i % (G::H + 2), i / (G::H + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias) {
+#pragma unroll
+          for (int kk = 0; kk < G::H; ++kk) accb = WH<T>::mfma(af[kk], ones, accb);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+          const int s = i / (G::H + 2), ri = i % (G::H + 2);
+          if (i + AHEAD < NSTEP) bring[(i + AHEAD) & 3] = rdX((i + AHEAD) % (G::H + 2), (i + AHEAD) / (G::H + 2));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int kk = ri - r;
+#ifndef WH_NO_MFMA
+            if (kk >= 0 && kk < G::H) acc[3 * r + s] = WH<T>::mfma(af[kk], bring[i & 3], acc[3 * r + s]);
+#else
+            if (kk >= 0 && kk < G::H) { acc[3 * r + s][0] += (float)af[kk][0] + (float)bring[i & 3][0]; }
+#endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -271,21 +304,19 @@ __global__ __launch_bounds__(LD ? 512 : 256, 2) void wgrad_h16_kernel(const WBat
 int srk_launch_wgrad_h16(const WBatch& B, int precision, float* part, float* pbias, hipStream_t st) {
   dim3 grid((unsigned)(B.P * B.n_chunks));
   const bool un = B.dy_mode == SRK_IN_UNSHUFFLE;
-  if (B.h16 == 2) {          // the loader form: one workgroup per CU (srk_wgrad.hip plans half as many pixel splits for it)
-    if (precision == 3) {
-      if (un) hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_UNSHUFFLE, true>), grid, dim3(512), 0, st, B, part, pbias);
-      else hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_PLAIN, true>), grid, dim3(512), 0, st, B, part, pbias);
-    } else {
-      if (un) hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_UNSHUFFLE, true>), grid, dim3(512), 0, st, B, part, pbias);
-      else hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_PLAIN, true>), grid, dim3(512), 0, st, B, part, pbias);
-    }
-  } else if (precision == 3) {
-    if (un) hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_UNSHUFFLE, false>), grid, dim3(256), 0, st, B, part, pbias);
-    else hipLaunchKernelGGL((wgrad_h16_kernel<_Float16, SRK_IN_PLAIN, false>), grid, dim3(256), 0, st, B, part, pbias);
+  // B.h16: 1 = two workgroups per CU; 2 = loader form (srk_wgrad.hip plans half as many pixel splits for it).  Both on 8-row tiles: the
+  // loader form on 16-row tiles (two stage buffers, WHG<16>) measured the same 157 us per dense block
+#define WH_LAUNCH(T, LD, TH, NT)                                                                                                       \
+  do {                                                                                                                                \
+    if (un) hipLaunchKernelGGL((wgrad_h16_kernel<T, SRK_IN_UNSHUFFLE, LD, TH>), grid, dim3(NT), 0, st, B, part, pbias);                  \
+    else hipLaunchKernelGGL((wgrad_h16_kernel<T, SRK_IN_PLAIN, LD, TH>), grid, dim3(NT), 0, st, B, part, pbias);                         \
+  } while (0)
+  if (precision == 3) {
+    if (B.h16 == 2) WH_LAUNCH(_Float16, true, 8, 512); else WH_LAUNCH(_Float16, false, 8, 256);
   } else {
-    if (un) hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_UNSHUFFLE, false>), grid, dim3(256), 0, st, B, part, pbias);
-    else hipLaunchKernelGGL((wgrad_h16_kernel<__bf16, SRK_IN_PLAIN, false>), grid, dim3(256), 0, st, B, part, pbias);
+    if (B.h16 == 2) WH_LAUNCH(__bf16, true, 8, 512); else WH_LAUNCH(__bf16, false, 8, 256);
   }
+#undef WH_LAUNCH
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
