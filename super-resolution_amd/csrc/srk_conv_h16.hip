@@ -732,8 +732,12 @@ typedef srk_chain_args h16_chain_args;
 #define H16_CHAIN_SIG_STEP 12
 #endif
 
+#ifndef CH_NLOAD_N
+#define CH_NLOAD_N 2
+#endif
+constexpr int CH_NLOAD = CH_NLOAD_N, CH_THREADS = 64 * (4 + CH_NLOAD);      // loader waves of the chain kernel
 template <typename T>
-__global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const h16_chain_args A) {
+__global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const h16_chain_args A) {
   constexpr int STORE_AUX = H16_AUX_SC1;
   typedef typename H16<T>::v8 v8;
   constexpr int MT = 4;
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
   if (wv >= 4) {
     // ------------------------------------------------------------------------------------------------------ loader waves
     const int lw = wv - 4;
-    constexpr int NXJ = (G::HPIECES + H16_NLOAD - 1) / H16_NLOAD, NWJ = G::WPIECES / H16_NLOAD;
+    constexpr int NXJ = (G::HPIECES + CH_NLOAD - 1) / CH_NLOAD, NWJ = G::WPIECES / CH_NLOAD;
     const unsigned wvo = (unsigned)(lane * 16);
     const srk_chain_watch watch = srk_chain_watch_of(A.flags, lane, n, ty, tx, tilesH, tilesW);     // lanes 0..8: the eight neighbouring tiles
     auto wait_flags = [&](unsigned target) { srk_chain_wait(watch, target, A.err, lane); };
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
       wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)((long)(a.Cin >> 5) * 36 * CoutP * 16), 0x00020000);
 #pragma unroll
       for (int j = 0; j < NXJ; ++j) {
-        const int hp = (lw + H16_NLOAD * j) * 16 + (lane >> 2);
+        const int hp = (lw + CH_NLOAD * j) * 16 + (lane >> 2);
         const int g = (lane & 3) ^ ((hp >> 2) & 3);
         const int hy = hp / HW_IW, hx = hp - hy * HW_IW;
         const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
@@ -792,19 +796,19 @@ __global__ __launch_bounds__(H16_THREADS, 2) void conv3x3_h16_chain_kernel(const
       if (dev) {
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
-          const int i = lw + H16_NLOAD * j;
+          const int i = lw + CH_NLOAD * j;
           if (i < G::HPIECES) h16_dma_dev(xrs, dst + i * 64, xvo[j], xso);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
-          const int i = lw + H16_NLOAD * j;
+          const int i = lw + CH_NLOAD * j;
           if (i < G::HPIECES) h16_dma(xrs, dst + i * 64, xvo[j], xso);
         }
       }
 #pragma unroll
       for (int j = 0; j < NWJ; ++j) {
-        const int w = lw + H16_NLOAD * j;
+        const int w = lw + CH_NLOAD * j;
         h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
       }
     };
@@ -1145,8 +1149,8 @@ int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) 
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
   const srk_conv_args& f = args[0];
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
-  if (f.wp_format == 7) hipLaunchKernelGGL(conv3x3_h16_chain_kernel<_Float16>, grid, dim3(H16_THREADS), 0, st, A);
-  else hipLaunchKernelGGL(conv3x3_h16_chain_kernel<__bf16>, grid, dim3(H16_THREADS), 0, st, A);
+  if (f.wp_format == 7) hipLaunchKernelGGL(conv3x3_h16_chain_kernel<_Float16>, grid, dim3(CH_THREADS), 0, st, A);
+  else hipLaunchKernelGGL(conv3x3_h16_chain_kernel<__bf16>, grid, dim3(CH_THREADS), 0, st, A);
   const bool ok = hipGetLastError() == hipSuccess;
   const int rc2 = srk_chain_end(st, ok);
   return ok ? (rc2 ? rc2 : 1) : SRK_ERR_LAUNCH;
