@@ -98,14 +98,17 @@ typedef struct srk_conv_args {
                                y, the conv writes (y > 0) per stored element here.  SRK_CONV_MASK_SIGNS: the LeakyReLU' mask comes from such
                                bits, written by an earlier conv of the SAME geometry (N, OH, OW, Cout) and format, instead of from `mask`
                                (which must be NULL): the data-gradient conv of a dense block then reads 1 MB instead of the 16.8 MB of the
-                               forward activation.  Same results as with the mask tensor.  (The fp32 F(2x4,3x3) kernel does not offer them:
-                               it has no register to spare.) */
+                               forward activation.  Same results as with the mask tensor.  (The fp32 F(2x4,3x3) kernel, wp_format 6, has no
+                               register to spare for them: srk_conv3x3_seq_signs_bytes says 0 there.) */
 } srk_conv_args;
 #define SRK_CONV_OUT_F32 1
 #define SRK_CONV_WRITE_SIGNS 2
 #define SRK_CONV_MASK_SIGNS 4
 /* bytes of the `signs` buffer for this conv (by its geometry, format and the kernel form its launch takes); 0: the launch does not support sign bits */
 size_t srk_conv3x3_signs_bytes(const srk_conv_args* a);
+/* the same for a whole srk_conv3x3_seq call (bytes of ONE conv's buffer; every conv of the sequence needs the same); 0: this sequence's
+ * launches offer no sign bits (the caller keeps passing the mask tensors) */
+size_t srk_conv3x3_seq_signs_bytes(const srk_conv_args* args, int n);
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
 /* n of them launched back to back on `stream`, in array order, from ONE call: the five forward (or five data-gradient) convolutions of

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3_signs_bytes", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3_signs_bytes", "srk_conv3x3_seq_signs_bytes", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -98,6 +98,8 @@ def lib():
         L.srk_conv3x3.argtypes = [C.POINTER(ConvArgs), _fp]
         L.srk_conv3x3_signs_bytes.restype = C.c_size_t
         L.srk_conv3x3_signs_bytes.argtypes = [C.POINTER(ConvArgs)]
+        L.srk_conv3x3_seq_signs_bytes.restype = C.c_size_t
+        L.srk_conv3x3_seq_signs_bytes.argtypes = [C.POINTER(ConvArgs), C.c_int]
         L.srk_adam_plan.argtypes = [C.POINTER(AdamEntry), C.c_int, C.POINTER(C.c_int64)]
         L.srk_adam_step.argtypes = [_fp, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
         L.srk_adam_step_small.argtypes = [C.POINTER(AdamEntry), C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
@@ -264,6 +266,15 @@ def conv_signs_bytes(x: View, wp, bias, y: View, **kw) -> int:
     a = ConvArgs()
     _fill_conv_args(a, x, wp, bias, y, **kw)
     return int(lib().srk_conv3x3_signs_bytes(C.byref(a)))
+
+
+def conv_seq_signs_bytes(calls) -> int:
+    """bytes of ONE conv's sign-bit buffer when the sequence `calls` (as for conv3x3_seq) offers sign bits, else 0"""
+    n = len(calls)
+    arr = (ConvArgs * n)()
+    for a, (x, wp, bias, y, kw) in zip(arr, calls):
+        _fill_conv_args(a, x, wp, bias, y, **kw)
+    return int(lib().srk_conv3x3_seq_signs_bytes(arr, n))
 
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):

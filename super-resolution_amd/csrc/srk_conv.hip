@@ -1094,6 +1094,7 @@ int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t 
 int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st);   // the same for the fp32 F(2x4,3x3) kernel (wp_format 6)
 int srk_conv_w42_chain_would(const srk_conv_args* args, int n);
 int srk_conv_w42_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
+size_t srk_conv_w42_chain_signs_bytes(const srk_conv_args* args, int n);
 int srk_conv_small_kind(const srk_conv_args& a);                          // srk_conv_small.hip
 int srk_launch_conv_small(const srk_conv_args& a, int kind, hipStream_t st);
 
@@ -1195,6 +1196,20 @@ extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
 extern "C" size_t srk_conv3x3_signs_bytes(const srk_conv_args* pa) {
   if (!pa || (pa->wp_format != 7 && pa->wp_format != 8)) return 0;
   return srk_conv_h16_signs_bytes(*pa);
+}
+
+// sign bits for a whole srk_conv3x3_seq call: bytes of ONE conv's buffer, 0 if this sequence's launches do not offer them (the fp32
+// F(2x4,3x3) kernel has them in its chain form only: a sequence that would go conv by conv has none)
+extern "C" size_t srk_conv3x3_seq_signs_bytes(const srk_conv_args* args, int n) {
+  if (!args || n <= 0) return 0;
+  const int fmt = args[0].wp_format;
+  if (fmt == 7 || fmt == 8) {
+    size_t b = srk_conv_h16_signs_bytes(args[0]);
+    for (int i = 1; i < n && b; ++i) if (srk_conv_h16_signs_bytes(args[i]) != b) b = 0;
+    return b;
+  }
+  if (fmt == 6 && n >= 2) return srk_conv_w42_chain_signs_bytes(args, n);
+  return 0;
 }
 
 // Name of the ONE kernel srk_conv3x3_seq would launch for the whole sequence (the chain form), or "" when it launches the convolutions

@@ -28,6 +28,9 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W42_CHAIN_SIGNS
+#define W42_CHAIN_SIGNS 0        // 1: sign bits (srk_conv_args.signs) in the chain kernels.  Correct (bit-identical to the mask tensors), but with
+#endif                           // them compiled in the 32-row chain kernel spills 131 registers around its exchange / epilogue: 455 -> 490 us per block
 #ifndef W42_STORE_AUX
 #define W42_STORE_AUX 0          // cache-policy bits of the one-conv kernels' 16-byte stores (A/B builds: 2 = nt, 16 = sc1)
 #endif
@@ -382,9 +385,15 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
-  // (sign bits -- srk_conv_args.signs, conv_epilogue's SIGNS -- are NOT offered by this kernel: with them the register allocation of the
-  // K loop changes, 4-68 spills depending on the instantiation; the 16-bit kernels have them)
-  conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : W42_STORE_AUX>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv);     // (16 = sc1: write-through)
+  // Sign bits (srk_conv_args.signs, conv_epilogue's SIGNS): not in the one-conv kernels (they change the register allocation of the K
+  // loop: 4-68 spills, depending on the instantiation), and in the chain kernels only as a build option (W42_CHAIN_SIGNS above).
+  int tile_e = 0;
+  if constexpr (CHAIN && W42_CHAIN_SIGNS) {
+    tile_e = blockIdx.x;
+    const int Tg = gridDim.x;
+    if ((Tg & 7) == 0) tile_e = (tile_e & 7) * (Tg >> 3) + (tile_e >> 3);
+  }
+  conv_epilogue<64, 2 * NMT, false, 16, 8, CHAIN ? 16 : W42_STORE_AUX, CHAIN && W42_CHAIN_SIGNS>(a, out, smem, n, oh0, ow0, n0, wv, lane, EXSLOTS + wv, tile_e);     // (16 = sc1: write-through)
   W42_STAMP(5);
   if constexpr (CHAIN) {
     // publish this conv of the tile: every wave has seen its (write-through) stores acknowledged by memory; the barrier also ends this
@@ -464,11 +473,24 @@ static bool w42_chain_eligible(const srk_conv_args* args, int n) {
     if (a.r2 && ((a.r2_ldc | a.r2_coff) & 3 || (((uintptr_t)a.r2) & 15))) return false;
     if (a.mask && ((a.m_ldc | a.m_coff) & 3 || (((uintptr_t)a.mask) & 15))) return false;
     if ((long)a.H * a.W * a.x_ldc * 4 > 0x7fffffffL) return false;
+    if (a.flags & (SRK_CONV_WRITE_SIGNS | SRK_CONV_MASK_SIGNS)) {        // sign bits (srk_conv_args.signs): the chain kernels have them
+      if (!W42_CHAIN_SIGNS || !a.signs || (((uintptr_t)a.signs) & 15)) return false;
+      if ((a.flags & SRK_CONV_WRITE_SIGNS) && (a.flags & SRK_CONV_MASK_SIGNS)) return false;
+      if ((a.flags & SRK_CONV_MASK_SIGNS) && a.mask) return false;
+    }
   }
   return srk_chain_pattern_ok(args, n, 4);
 }
 
 int srk_conv_w42_chain_would(const srk_conv_args* args, int n) { return w42_chain_eligible(args, n) ? 1 : 0; }
+
+// bytes of one conv's sign-bit buffer when the sequence goes out as a chain kernel (which has sign bits); 0 otherwise
+size_t srk_conv_w42_chain_signs_bytes(const srk_conv_args* args, int n) {
+  if (!W42_CHAIN_SIGNS || !w42_chain_eligible(args, n)) return 0;
+  const srk_conv_args& f = args[0];
+  const size_t tiles = (size_t)f.N * srk_div_up(f.H, 16 * srk_conv_wino42_nmt(f)) * srk_div_up(f.W, SRK_TW);
+  return tiles * 4 * 64 * 16;
+}
 
 int srk_conv_w42_chain_name(const srk_conv_args* args, int n, char* buf, size_t len) {
   (void)n;

@@ -119,9 +119,9 @@ class GeneratorEngine:
     def __getstate__(self):
         """Pickling / torch.save(module) / multiprocessing spawn: everything but the module reference and the flags is a cache
         (packed weights, pack tables, graphs, streams) that is rebuilt on the first forward."""
-        keep = ("gen", "_sync", "_grad_scale", "precision", "use_graphs", "_overlap_env", "_dp_serial")
+        keep = ("gen", "_sync", "_grad_scale", "precision", "use_graphs", "_overlap_env", "_dp_serial", "sign_bits")
         st = {k: self.__dict__[k] for k in keep}
-        st.update(_sig=None, _graphs={}, _side=None, _issue=None)
+        st.update(_sig=None, _graphs={}, _side=None, _issue=None, _signs_bytes={})
         return st
 
     # ------------------------------------------------------------------ data-parallel gradient exchange
@@ -369,27 +369,16 @@ class GeneratorEngine:
     # ------------------------------------------------------------------ building blocks
     def _drb_forward(self, d, pk: DrbPack, D, out: View, geo, outer_x: Optional[View], rs: float, save: bool = False):
         """One DenseResidualBlock on dense buffer D (slice 0 = block input).  ``outer_x`` is the RRDB input
-        for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53).  ``save`` (16-bit storage): convs 1-4
-        also write the SIGN BITS of their outputs (srk_conv_args.signs: 1 MB instead of the 16.8 MB slice), which the block's
-        data-gradient convolutions take their LeakyReLU' masks from."""
+        for the third block (its conv5 epilogue also applies ``*res_scale + x``, models.py:53).  ``save``: convs 1-4 also write the SIGN
+        BITS of their outputs (srk_conv_args.signs: 1 MB instead of the 16.8 / 33.5 MB slice) where the launches offer them; the
+        block's data-gradient convolutions then take their LeakyReLU' masks from those.  (Whether they do is decided once per geometry
+        and precision: the chain switches are process-wide settings, not something that changes between iterations.)"""
         N, H, W = geo
         F_ = pk.F
         calls = []          # the block's five convolutions go to the library in ONE call (srk_conv3x3_seq)
-        signs = None
-        if save and self.precision in H16_DTYPE and self.sign_bits:
-            key = (N, H, W, F_, self.precision)
-            nb = self._signs_bytes.get(key)
-            if nb is None:
-                nb = self._signs_bytes[key] = L.conv_signs_bytes(View(D, 0, F_), self.wf(pk.fwd[1]), None, View(D, F_, F_), N=N, H=H, W=W,
-                                                               OH=H, OW=W, Cin=F_, Cout=F_, slope=G_SLOPE)
-            if nb > 0:
-                signs = torch.empty(4, nb, dtype=torch.uint8, device=D.device)
-        D._srk_signs = signs
         for k in range(1, 5):
-            kw = dict(N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)
-            if signs is not None:
-                kw["signs_out"] = signs[k - 1]
-            calls.append((View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_), kw))
+            calls.append((View(D, 0, k * F_), self.wf(pk.fwd[k]), getattr(d, f"b{k}")[0].bias.data, View(D, k * F_, F_),
+                          dict(N=N, H=H, W=W, OH=H, OW=W, Cin=k * F_, Cout=F_, slope=G_SLOPE)))
         b5 = d.b5[0].bias.data
         if outer_x is None:
             calls.append((View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
@@ -397,6 +386,19 @@ class GeneratorEngine:
         else:
             calls.append((View(D, 0, 5 * F_), self.wf(pk.fwd[5]), b5, out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
                           alpha=INNER_RES_SCALE * rs, r1=View(D, 0, F_), beta1=rs, r2=outer_x, beta2=1.0)))
+        # sign bits of the outputs of convs 1-4 for the block's data-gradient convolutions (1 MB per conv instead of the 16.8 / 33.5 MB
+        # slice), where this sequence's launches offer them (16-bit storage: always; fp32: when it goes out as a chain kernel)
+        signs = None
+        if save and self.sign_bits and not self.use_graphs:
+            key = ("f", N, H, W, F_, self.precision, calls[0][1].fmt)
+            nb = self._signs_bytes.get(key)
+            if nb is None:
+                nb = self._signs_bytes[key] = L.conv_seq_signs_bytes(calls)
+            if nb > 0:
+                signs = torch.empty(4, nb, dtype=torch.uint8, device=D.device)
+                for k in range(4):
+                    calls[k][4]["signs_out"] = signs[k]
+        D._srk_signs = signs
         L.conv3x3_seq(calls)
 
     def _drb_backward(self, d, pk: DrbPack, D, E, gx_out: View, geo, beta_self: float, outer_g: Optional[View], grads: Dict):
@@ -405,15 +407,27 @@ class GeneratorEngine:
         N, H, W = geo
         F_ = pk.F
         calls = []          # the five data-gradient convolutions in ONE library call
-        signs = getattr(D, "_srk_signs", None)        # written by the block's forward convolutions (16-bit storage)
-        for m in range(4, 0, -1):
-            K = (5 - m) * F_
-            kw = dict(N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_, mask_slope=G_SLOPE)
-            if signs is not None:
-                kw["mask_signs"] = signs[m - 1]
-            else:
-                kw["mask"] = View(D, m * F_, F_)
-            calls.append((View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), kw))
+        signs = getattr(D, "_srk_signs", None)        # written by the block's forward convolutions
+        for use_signs in ((True, False) if signs is not None else (False,)):
+            calls = []
+            for m in range(4, 0, -1):
+                K = (5 - m) * F_
+                kw = dict(N=N, H=H, W=W, OH=H, OW=W, Cin=K, Cout=F_, mask_slope=G_SLOPE)
+                if use_signs:
+                    kw["mask_signs"] = signs[m - 1]
+                else:
+                    kw["mask"] = View(D, m * F_, F_)
+                calls.append((View(E, 0, K), self.wb(pk.bwd[m]), None, View(E, K, F_), kw))
+            if not use_signs:
+                break
+            # (fp32: only the chain form of THIS sequence reads sign bits; decided once per geometry)
+            key = ("b", N, H, W, F_, self.precision, calls[0][1].fmt)
+            ok = self._signs_bytes.get(key)
+            if ok is None:
+                ok = self._signs_bytes[key] = L.conv_seq_signs_bytes(calls + [(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out,
+                                                                               dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_))])
+            if ok > 0:
+                break
         calls.append((View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
                       r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)))
         L.conv3x3_seq(calls)

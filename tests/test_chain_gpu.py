@@ -179,3 +179,17 @@ def test_chain_form_is_skipped_under_stream_capture(U):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(D, refD) and torch.equal(out, refO)
+
+
+
+def test_wino42_offers_no_sign_bits(U):
+    """srk_conv_args.signs is a feature of the 16-bit kernels (tests/test_h16_gpu.py); the fp32 F(2x4,3x3) kernels have no register to
+    spare for it (built into their chain form it was correct and 8 % slower): the probe says 0 and the engine keeps the mask tensors"""
+    L = U.L
+    D, out, calls, keep = _block(U, 2, 64, 48, False, 970)
+    assert _seq_kernel(L, calls).startswith("conv3x3_f32_wino42_chain_kernel<")
+    assert L.conv_seq_signs_bytes(calls) == 0
+    signs = torch.zeros(4, 4096, dtype=torch.uint8, device="cuda")
+    cs = [(x, wp, b, y, dict(kw, signs_out=signs[k]) if k < 4 else kw) for k, (x, wp, b, y, kw) in enumerate(calls)]
+    with pytest.raises(RuntimeError):
+        L.conv3x3_seq(cs)

@@ -57,6 +57,7 @@ def main():
     inside = False
     prev = []          # the last two real instructions: (mnemonic, dst registers)
     vmem = []          # vector-memory instructions of the current kernel in program order
+    prev_text = ""
     last_wait = None   # the s_waitcnt ... vmcnt(N) directly in front of the current instruction, if any
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
@@ -88,7 +89,10 @@ def main():
                 bad += 1
                 print("VMCNT: `%s` + s_barrier does not sit behind [halo DMA piece, %d weight loads]; last vector-memory ops: %s"
                       % (last_wait, n, [v.split()[0] + (" lds" if " lds" in v else "") for v in vmem[-n - 1:]]))
-        last_wait = t if re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", t) and not t.endswith("(0)") else None     # (counted, vmcnt only)
+        # (counted, vmcnt only; a counted wait right behind a `vmcnt(0)` is the compiler's own, weaker, and means nothing)
+        counted = re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", t) and not t.endswith("(0)") and prev_text != "s_waitcnt vmcnt(0)"
+        last_wait = t if counted else None
+        prev_text = t
         if mn.startswith("v_mfma"):
             total += 1
             src = regs(ops[1]) | regs(ops[2])
