@@ -28,6 +28,9 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W42_CH_PREFETCH1
+#define W42_CH_PREFETCH1 0       // 1: chain form of the 16-row kernel: prefetch across the link boundary (PF in wino42_body).  It has the registers
+#endif                           // (no spill), so this is what the 32-row kernel could gain: block 276.0 -> 273.9 / 284.8 -> 277.7 us, step 60.9 -> 61.5 ms
 #ifndef W42_CHAIN_SIGNS
 #define W42_CHAIN_SIGNS 0        // 1: sign bits (srk_conv_args.signs) in the chain kernels.  Correct (bit-identical to the mask tensors), but with
 #endif                           // them compiled in the 32-row chain kernel spills 131 registers around its exchange / epilogue: 455 -> 490 us per block
@@ -62,8 +65,11 @@ __device__ unsigned long long* g_w42_stamps = nullptr;
 // CHAIN: the body as one link of the chain kernel below (srk_chain.h): conv c of the launch A.  Its outputs are stored write-through
 // and published through the tile's flag; (c > 0) the chunks of its last 64 input channels are fetched behind the wait for the
 // neighbouring tiles' flags of conv c - 1.
+// PF (chain form of the 16-row kernel, which has registers to spare -- 428 of 512): a link fetches its successor's first halo chunk and
+// first weights in front of its own epilogue (carryP0 = the kernel's copy of those weights); the 32-row kernel cannot afford it.
 template <int MODE, int NMT, bool CHAIN = false>
-__device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0) {
+__device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0, f32x2 (*carryP0)[6][2] = nullptr) {
+  constexpr bool PF = CHAIN && NMT == 1 && W42_CH_PREFETCH1 != 0;
   constexpr int TH = 16 * NMT, IH = TH + 2, IW = SRK_TW + 2;
   constexpr int HS4 = NMT == 2 ? 640 : 384;         // slots per k-half: 37 per row pair (17 resp. 9 pairs), padded to whole instructions
   constexpr int BUF4 = 2 * HS4;                     // 1280 float4 = 20 KB (NMT 2) / 768 = 12 KB (NMT 1) per chunk
@@ -111,15 +117,17 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   const unsigned vB = (unsigned)((hl * CoutP + n0 + l32) * 8);
   const unsigned sB_c = (unsigned)(2 * CoutP * 8);              // one column position
   const unsigned sB_ep = 24u * sB_c;                            // one channel pair of the chunk's k-halves
-  f32x2 P0[6][2], P1[6][2];          // weights of channels (0,1) resp. (2,3) of the chunk's k-halves: [c][nh]
+  f32x2 P0own[6][2], P1[6][2];       // weights of channels (0,1) resp. (2,3) of the chunk's k-halves: [c][nh]
+  f32x2 (&P0)[6][2] = *[&]() { if constexpr (PF) return carryP0; else return &P0own; }();
+  const bool fresh_start = !PF || c == 0;          // (PF, c > 0: the previous link has issued this conv's first weights and halo chunk)
   // the first weights need nothing but the lane id: they are on their way before the halo address arithmetic starts
-  {
+  if (fresh_start) {
     const unsigned so = (unsigned)wv * 6u * sB_c;
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int cc = 0; cc < 6; ++cc)
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
-        P0[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
+        P0[cc][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + cc * sB_c, 0));
   }
   __builtin_amdgcn_sched_barrier(0);
   unsigned vo[NPC];
@@ -292,8 +300,10 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     }
   };
 
-  piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{});
-  if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
+  if (fresh_start) {
+    piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{});
+    if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
+  }
   W42_STAMP(1);
   __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
 #pragma unroll
@@ -301,8 +311,17 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (PF) {
+    // c > 0: the chunk and the weights were issued in front of the previous epilogue, which has issued its 16 stores (and its residual /
+    // mask loads) behind them.  Vector-memory operations retire in order: with at most 16 outstanding everything older has landed -- no
+    // waiting for the write-through acknowledgements here.  (A bare barrier: __syncthreads()' release fence would wait for them after all.)
+    static_assert(2 * (2 * NMT) * 4 == 16 || !PF, "conv_epilogue_vec issues NI = NTN x MT x 4 stores");
+    if (fresh_start) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   W42_STAMP(2);
   {
     float d[6];
@@ -385,6 +404,22 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   }
   W42_STAMP(4);
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (PF) {
+    if (c + 1 < A->n) {
+      // the next conv's first halo chunk (channels 0..7 of the same input view: an old slice) and first weights, beside this epilogue.
+      // The barrier: every wave has taken its last read of the exchange area, which the chunk overwrites.
+      __builtin_amdgcn_s_barrier();
+      piece(0, 0, I0{}); piece(0, 0, I1{}); piece(0, 0, I2{});
+      const srk_conv_args& an = A->c[c + 1];
+      const __amdgpu_buffer_rsrc_t wn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(an.wp), 0, (unsigned)((long)((an.Cin + 7) >> 3) * 96 * CoutP * 8), 0x00020000);
+      const unsigned so = (unsigned)wv * 6u * sB_c;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          P0[cc][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wn, vB + nh * 256, so + cc * sB_c, 0));
+    }
+  }
   // Sign bits (srk_conv_args.signs, conv_epilogue's SIGNS): not in the one-conv kernels (they change the register allocation of the K
   // loop: 4-68 spills, depending on the instantiation), and in the chain kernels only as a build option (W42_CHAIN_SIGNS above).
   int tile_e = 0;
@@ -418,7 +453,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_
 // same order: bit-identical results.
 template <int NMT>
 __global__ __launch_bounds__(256) void conv3x3_f32_wino42_chain_kernel(const srk_chain_args A) {
-  for (int c = 0; c < A.n; ++c) wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c);
+  f32x2 P0[6][2];          // (16-row form: the next conv's first weights, fetched by the previous link)
+  for (int c = 0; c < A.n; ++c) wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0);
 }
 
 }  // namespace
@@ -467,6 +503,7 @@ static bool w42_chain_eligible(const srk_conv_args* args, int n) {
   for (int c = 0; c < n; ++c) {
     const srk_conv_args& a = args[c];
     if (a.wp_format != 6 || a.Cout != 64 || srk_conv_wino42_nmt(a) != nmt || (((uintptr_t)a.wp) & 15)) return false;
+    if (a.x != f.x || a.x_ldc != f.x_ldc || a.x_coff != f.x_coff) return false;      // one input view (a link may prefetch its successor's first chunk)
     // the epilogue's 16-byte path (the one that stores write-through): srk_epilogue.h `vec_out`
     if (a.bias && (((uintptr_t)a.bias) & 15)) return false;
     if (a.r1 && ((a.r1_ldc | a.r1_coff) & 3 || (((uintptr_t)a.r1) & 15))) return false;
