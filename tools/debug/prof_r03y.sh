@@ -1,7 +1,7 @@
 # rocprofv3 evidence for the chain form (round 3, second half): kernel-trace stats of the c4 workload (serial schedule: one stream, so
 # that kernel durations are not inflated by co-running launches), HBM traffic of its kernels, then the default bench line
 set -o pipefail
-out=gpurun_out/r03y
+out=gpurun_out/r03final_c4
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 C4="python3 bench.py --workload c4 --steps 3 --warmup 2 --no-alt --no-cpu-baseline --no-kernel-timing"
