@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Data-gradient chain of a dense block (16-bit storage, 8 x 128 x 128) with the LeakyReLU' masks read from the forward activations vs
-from sign bits, and the forward chain with / without writing the bits."""
+"""Data-gradient chain of a dense block (FMT=7|8: 16-bit storage, 8 x 128 x 128; FMT=6: fp32 F(2x4,3x3), 32 x 64 x 64) with the LeakyReLU'
+masks read from the forward activations vs from sign bits, and the forward chain with / without writing the bits."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import chain_check as cc
 L = cc.L
-N, H = 8, 128
+N, H = (32, 64) if cc.fmt == 6 else (8, 128)
 
 
 def timed(blocks):
@@ -19,11 +19,11 @@ def timed(blocks):
     return e0.elapsed_time(e1) / 60 * 1e3
 
 
-L.lib().srk_debug_set_h16_chain(1)
+cc.set_chain(1)
 fw = [cc.make_block(N, H, H, 100 + i, False) for i in range(6)]
 bw = [cc.make_block(N, H, H, 200 + i, True) for i in range(6)]
-c0 = fw[0][2][0]
-nb = L.conv_signs_bytes(c0[0], c0[1], c0[2], c0[3], **c0[4])
+nb = L.conv_seq_signs_bytes(fw[0][2])
+assert nb > 0, "this build offers no sign bits for this format"
 sg = [torch.zeros(4, nb, dtype=torch.uint8, device="cuda") for _ in range(6)]
 fw_plain = [b[2] for b in fw]
 fw_signs = [[(x, wp, b_, y, dict(kw, signs_out=sg[i][k]) if k < 4 else kw) for k, (x, wp, b_, y, kw) in enumerate(b[2])] for i, b in enumerate(fw)]
