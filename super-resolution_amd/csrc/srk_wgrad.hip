@@ -1177,7 +1177,7 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
   if (a0.precision == 1 || a0.precision == 2) { snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d>", a0.dy_mode, a0.precision == 1 ? 3 : 1); return SRK_OK; }
   if (a0.precision == 3 || a0.precision == 4) { snprintf(buf, len, "wgrad_h16_kernel<%s, %d>", a0.precision == 3 ? "_Float16" : "__bf16", a0.dy_mode); return SRK_OK; }
-  if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d>", a0.dy_mode); return SRK_OK; }
+  if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d, %s>", a0.dy_mode, srk_wgrad_wino22_rows() ? "true" : "false"); return SRK_OK; }
   if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
   int ksp = 1;
   if (a0.dy_mode == SRK_IN_PLAIN) {

@@ -44,4 +44,5 @@ constexpr int W16_TH = 8;                                  // pixel rows per til
 }  // namespace srkw
 
 int srk_launch_wgrad_wino22(const srkw::WBatch& B, float* part, float* pbias, hipStream_t st);
+int srk_wgrad_wino22_rows();            // 1: the row-owner form of the kernel is the one launched
 int srk_launch_wgrad_h16(const srkw::WBatch& B, int precision, float* part, float* pbias, hipStream_t st);   // precision 3 (fp16) / 4 (bf16)

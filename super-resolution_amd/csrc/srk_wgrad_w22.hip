@@ -29,6 +29,9 @@ constexpr int W22_THREADS = 256;
 #define W22_XS1 11
 #define W22_XG 5
 #endif
+#ifndef W22_NPS
+#define W22_NPS 1        // row-owner form: DMA pieces per vector-ALU gap (1: a tile's 20 pieces per wave ride on ten k-steps; 2: on five)
+#endif
 
 #ifdef SRK_STAMP      // diagnostic build (make stamp; tools/stamp_w22.py): per-workgroup phase stamps.  Only OUTSIDE the tile loop: a chained node
                       // (s_memtime, volatile asm) inside it makes the instruction selector abandon the source order of the builtin MFMAs
@@ -38,7 +41,7 @@ __device__ unsigned long long* g_w22_stamps = nullptr;
 #define W22_STAMP(k) do { } while (0)
 #endif
 
-template <int DYMODE>
+template <int DYMODE, bool ROWS>
 __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBatch B, float* part, float* pbias) {
   __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];     // 163,840 B: all of the LDS
   const int tid = threadIdx.x, lane = tid & 63;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     wdma16(isdy ? c.dr : c.xr, dst, ok ? off : W_OOB);
   };
 
+  if constexpr (!ROWS) {
   // per-lane LDS offsets (floats) of patch (row 0, columns 2 * 0 + hl)
   const int aoff = (2 * hl) * 64 + 32 * wa + l32;                              // dy pixel (0, 2 hl)
   const int boff = W22_TP * 64 + (2 * hl) * 64 + 32 * wb + l32;                // halo pixel (0, 2 hl)
@@ -323,16 +327,214 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     const float tot = bsum + __shfl_xor(bsum, 32);
     if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
+  } else {
+  // =====================================================================================================================
+  // ROW-OWNER form.  Wave wv owns ROW wv of the 4 x 4 positions for the whole 64 x 64 chunk (2 cout tiles x 2 cin tiles x 4
+  // positions = the same 16 accumulator tiles), instead of all 16 positions of one 32 x 32 tile.  A row of U = A g A^T and of
+  // V = B^T d B needs only ONE combination of two raw rows (row pass first: t_j = d[ra][j] + s d[rb][j], with (ra, rb, s) wave-
+  // uniform -- two LDS base offsets and one scalar coefficient, so the four waves run the SAME code), then the four column
+  // combinations: 4 + 4 VALU per cin tile, 2 + 2 per cout tile = 24 per 16 MFMAs instead of 36-44, for 24 instead of 12-20 LDS
+  // dwords (free beside fp32 MFMAs, which vector-ALU work is not).  The rows meet in G^T M G at the end, through the LDS.
+  //   B^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3);  A rows: (g0, g0 + g1, g0 - g1, g1)
+  const int xra = wv == 0 ? 0 : (wv == 2 ? 2 : 1);
+  const int xrb = wv == 0 ? 2 : (wv == 1 ? 2 : (wv == 2 ? 1 : 3));
+  const float xs = wv == 1 ? 1.f : -1.f;
+  const int dra = wv == 3 ? 1 : 0;
+  const int drb = (wv == 1 || wv == 2) ? 1 : dra;
+  const float dsc = wv == 1 ? 1.f : (wv == 2 ? -1.f : 0.f);
+  const int aoffA = (2 * hl) * 64 + l32 + dra * 16 * 64, aoffB = (2 * hl) * 64 + l32 + drb * 16 * 64;
+  // (the second cout tile's dy base is opaque: seen as aoffA + 32, the two tiles' reads are paired into ds_read2_b32, whose 8-bit
+  // offsets need a v_add per k-step for the base -- a third vector-ALU gap; unrelated bases pair along j, as ds_read2st64_b32
+  // with the whole step offset in the instruction)
+  int aoffA1 = aoffA + 32, aoffB1 = aoffB + 32;
+  asm volatile("" : "+v"(aoffA1), "+v"(aoffB1));
+  const int boffA = W22_TP * 64 + (2 * hl) * 64 + l32 + xra * W22_IW * 64, boffB = W22_TP * 64 + (2 * hl) * 64 + l32 + xrb * W22_IW * 64;
+  float bs0 = 0.f, bs1 = 0.f;
+  // operands: U[4 m + q] (cout tile m), V[4 n + q] (cin tile n); raw values gA/gB[2 m + j], dA/dB[4 n + j]
+  float U0[8], V0[8], U1[8], V1[8], gA[4], gB[4], dA[8], dB[8];
+  auto rd_g = [&](int bb, int kk) {
+    const int pr = kk & 3, cp = kk >> 2;
+    const int o = bb * W22_TILE_FLOATS + ((2 * pr) * 16 + 4 * cp) * 64;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gA[2 * m + j] = smem[(m ? aoffA1 : aoffA) + o + 64 * j];
+        gB[2 * m + j] = smem[(m ? aoffB1 : aoffB) + o + 64 * j];
+      }
+  };
+  auto rd_d = [&](int bb, int kk, int n, bool second) {
+    const int pr = kk & 3, cp = kk >> 2;
+    const float* q = smem + bb * W22_TILE_FLOATS + (second ? boffB : boffA) + ((2 * pr) * W22_IW + 4 * cp) * 64 + 32 * n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) (second ? dB : dA)[4 * n + j] = q[64 * j];
+  };
+  auto xf_u = [&](float (&U)[8], bool count_bias) {                // 8 VALU + 2 (bias: row 1, position 1 IS the patch sum)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      U[4 * m + 0] = __builtin_fmaf(dsc, gB[2 * m + 0], gA[2 * m + 0]);
+      U[4 * m + 3] = __builtin_fmaf(dsc, gB[2 * m + 1], gA[2 * m + 1]);
+      U[4 * m + 1] = U[4 * m + 0] + U[4 * m + 3];
+      U[4 * m + 2] = U[4 * m + 0] - U[4 * m + 3];
+    }
+    bs0 += count_bias ? U[1] : 0.f;
+    bs1 += count_bias ? U[5] : 0.f;
+  };
+  float tt[8];
+  auto xf_vrow = [&](int n) {                                      // 4 VALU
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tt[4 * n + j] = __builtin_fmaf(xs, dB[4 * n + j], dA[4 * n + j]);
+  };
+  auto xf_vcol = [&](float (&V)[8], int n) {                       // 4 VALU
+    V[4 * n + 0] = tt[4 * n + 0] - tt[4 * n + 2]; V[4 * n + 1] = tt[4 * n + 1] + tt[4 * n + 2];
+    V[4 * n + 2] = tt[4 * n + 2] - tt[4 * n + 1]; V[4 * n + 3] = tt[4 * n + 1] - tt[4 * n + 3];
+  };
+  TilePos pos2;
+  TileCtx c2;
+  auto kstep = [&](const float (&U)[8], const float (&V)[8], int nb, int nk, float (&UN)[8], float (&VN)[8],
+                   const TileCtx& dc, int db, int dj, bool dlive, bool next_real, int mk = 0, bool mk_go = false) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                 // accumulator tile i = 4 q + 2 m + n
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[4 * ((i >> 1) & 1) + (i >> 2)], V[4 * (i & 1) + (i >> 2)], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef W22_NO_LDS
+      if (i == 0) rd_g(nb, nk);
+      if (i == 1) rd_d(nb, nk, 0, false);
+      if (i == 2) rd_d(nb, nk, 0, true);
+      if (i == 4) rd_d(nb, nk, 1, false);
+      if (i == 5) rd_d(nb, nk, 1, true);
+#endif
+      if (mk == 1 && i == 3) { pos_step(pos2, mk_go); ctx_offsets(pos2, c2); ctx_rsrcs(pos2, c2); }
+#ifndef W22_NO_XFORM
+      if (i == W22_XS0) { xf_u(UN, next_real); xf_vrow(0); }
+      if (i == W22_XS1) { xf_vcol(VN, 0); xf_vrow(1); xf_vcol(VN, 1); }
+#endif
+#ifndef W22_NO_DMA
+      if (dj >= 0 && dj < NPW / (2 * W22_NPS) && i == W22_XS0) {
+#pragma unroll
+        for (int u = 0; u < W22_NPS; ++u) piece(dc, db, 2 * W22_NPS * dj + u, dlive);
+      }
+      if (dj >= 0 && dj < NPW / (2 * W22_NPS) && i == W22_XS1) {
+#pragma unroll
+        for (int u = 0; u < W22_NPS; ++u) piece(dc, db, 2 * W22_NPS * dj + W22_NPS + u, dlive);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  TileCtx cn;
+  if (t_begin < t_end) {
+    pos2 = tile_pos(t_begin);
+    TileCtx c0;
+    ctx_offsets(pos2, c0); ctx_rsrcs(pos2, c0);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) piece(c0, 0, j, true);
+    pos_step(pos2, t_begin + 1 < t_end);
+    ctx_offsets(pos2, cn); ctx_rsrcs(pos2, cn);
+    c2 = cn;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+  if (t_begin < t_end) {
+    if (t_begin + 1 < t_end) {
+#pragma unroll
+      for (int u = 0; u < 2 * W22_NPS; ++u) piece(cn, 1, u, true);
+    }
+    rd_g(0, 0);
+    rd_d(0, 0, 0, false); rd_d(0, 0, 0, true); rd_d(0, 0, 1, false); rd_d(0, 0, 1, true);
+    xf_u(U0, true);
+    xf_vrow(0); xf_vcol(V0, 0); xf_vrow(1); xf_vcol(V0, 1);
+  }
+  int b = 0;
+  W22_STAMP(1);
+  for (int tile = t_begin; tile < t_end; ++tile) {                 // (the tile pipeline of the form above)
+    const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
+    const bool livep = more1;
+    const int bnp = b ^ 1;
+#pragma unroll
+    for (int kk = 0; kk < 14; kk += 2) {
+      kstep(U0, V0, b, kk + 1, U1, V1, cn, bnp, kk < 9 ? kk + 1 : -1, livep, true, kk == 10 ? 1 : 0, more2);
+      kstep(U1, V1, b, kk + 2, U0, V0, cn, bnp, kk + 1 < 9 ? kk + 2 : -1, livep, true, 0, false);
+    }
+    kstep(U0, V0, b, 15, U1, V1, cn, bnp, -1, false, true);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    kstep(U1, V1, bnp, 0, U0, V0, c2, b, 0, more2, more1);
+    cn = c2;
+    b ^= 1;
+  }
+  W22_STAMP(2);
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+
+  // G^T M G: the column pass (over q) inside the wave, the row pass (over the four waves) through the LDS, one cout tile per
+  // round (4 waves x 2 cin tiles x 16 registers x 3 values x 64 lanes = 96 KB).  Round m, wave w then combines cin tile w & 1,
+  // registers 8 (w >> 1) .. + 7 and stores the nine taps.
+  float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (m) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float m0 = acc[2 * m + n][e], m1 = acc[4 + 2 * m + n][e], m2 = acc[8 + 2 * m + n][e], m3 = acc[12 + 2 * m + n][e];
+        const float hs = 0.5f * (m1 + m2);
+        float* o = smem + ((wv * 2 + n) * 16 + e) * 192 + lane;
+        o[0] = m0 + hs; o[64] = 0.5f * (m1 - m2); o[128] = hs - m3;
+      }
+    __syncthreads();
+    const int n = wv & 1;
+    const bool tile_ok = (cout0 + 32 * m < a.Cout) && (cin0 + 32 * n < a.Cin);
+    if (tile_ok) {
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        const int e = 8 * (wv >> 1) + e8;
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * hl;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          const float* q = smem + (n * 16 + e) * 192 + sx * 64 + lane;
+          const float T0 = q[0], T1 = q[2 * 16 * 192], T2 = q[4 * 16 * 192], T3 = q[6 * 16 * 192];
+          const float hs = 0.5f * (T1 + T2);
+          dst[((sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = T0 + hs;
+          dst[((3 + sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = 0.5f * (T1 - T2);
+          dst[((6 + sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = hs - T3;
+        }
+      }
+    }
+  }
+  if (a.db != nullptr && cy == 0 && wv == 1) {
+    const float t0 = bs0 + __shfl_xor(bs0, 32), t1 = bs1 + __shfl_xor(bs1, 32);
+    float* pb = pbias + ((size_t)p * B.n_chunks + chunk) * 64 + l32;
+    if (hl == 0 && cout0 < a.Cout) pb[0] = t0;
+    if (hl == 0 && cout0 + 32 < a.Cout) pb[32] = t1;
+  }
+  }
   W22_STAMP(3);
 }
 
 }  // namespace
 
+// Which form of the kernel is launched: 1 (default) the row-owner form, 0 the tile-owner form (every wave forms all 16 positions of
+// its own 32 x 32 tile).  SRK_WGRAD_W22_FORM / srk_debug_set_wgrad_w22_form (A/B measurements, tests).
+static int g_w22_rows = -1;
+int srk_wgrad_wino22_rows() {
+  if (g_w22_rows < 0) { const char* e = getenv("SRK_WGRAD_W22_FORM"); g_w22_rows = e ? (atoi(e) != 0) : 1; }
+  return g_w22_rows;
+}
+extern "C" int srk_debug_set_wgrad_w22_form(int rows) { g_w22_rows = rows < 0 ? -1 : (rows != 0); return SRK_OK; }
+
 int srk_launch_wgrad_wino22(const WBatch& B, float* part, float* pbias, hipStream_t st) {
-  if (B.dy_mode == SRK_IN_UNSHUFFLE)
-    hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE>), dim3(B.P * B.n_chunks), dim3(W22_THREADS), 0, st, B, part, pbias);
-  else
-    hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN>), dim3(B.P * B.n_chunks), dim3(W22_THREADS), 0, st, B, part, pbias);
+  const int rows = srk_wgrad_wino22_rows();
+  const dim3 grid(B.P * B.n_chunks), blk(W22_THREADS);
+  if (B.dy_mode == SRK_IN_UNSHUFFLE) {
+    if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE, true>), grid, blk, 0, st, B, part, pbias);
+    else hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE, false>), grid, blk, 0, st, B, part, pbias);
+  } else {
+    if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN, true>), grid, blk, 0, st, B, part, pbias);
+    else hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN, false>), grid, blk, 0, st, B, part, pbias);
+  }
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }

@@ -179,6 +179,31 @@ def test_conv_wgrad(U, ci, co, h, w, stride, n):
     assert U.rel_err(dw.cpu(), 1.5 * wt.grad) < TOL
 
 
+@pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 15, 17, 2), (320, 64, 64, 64, 2), (96, 64, 33, 3, 1), (64, 192, 1, 1, 3), (128, 128, 7, 9, 1)])
+def test_conv_wgrad_wino22_forms(U, ci, co, h, w, n):
+    """Both forms of the 2-D Winograd weight-gradient kernel (row-owner: the default; tile-owner) against the oracle, and against
+    each other to rounding (they add the same products, the transforms in a different order)."""
+    L = U.L
+    x = _rand((n, ci, h, w), 31)
+    wt = _rand((co, ci, 3, 3), 32, 0.05).requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    y = O.conv3x3(x, wt, b)
+    dy = _rand(y.shape, 33)
+    y.backward(dy)
+    got = []
+    try:
+        for form in (1, 0):
+            L.lib().srk_debug_set_wgrad_w22_form(form)
+            dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+            db = torch.full((co,), float("nan"), device="cuda")
+            L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co)
+            assert U.rel_err(dw.cpu(), wt.grad) < TOL and U.rel_err(db.cpu(), b.grad) < TOL, form
+            got.append((dw.cpu(), db.cpu()))
+    finally:
+        L.lib().srk_debug_set_wgrad_w22_form(-1)
+    assert U.rel_err(got[0][0], got[1][0]) < 1e-5 and U.rel_err(got[0][1], got[1][1]) < 1e-5
+
+
 def test_conv_wgrad_unshuffle_wino(U):
     """upsampling conv at F=64 (Cout = 256): dy read through SRK_IN_UNSHUFFLE by the Winograd weight-gradient kernel."""
     L = U.L
