@@ -1,10 +1,11 @@
 // srk_wgrad_w22.hip -- the 2-D Winograd weight-gradient kernel ("wino22") for gfx950.  Its own translation unit because it is
-// built without packed-f32 VALU instructions (the operand transforms run in the shadow of MFMAs, where a v_pk_add_f32 costs
-// more issue time than the two scalar adds it replaces: 657 -> 638 us on the dense-block batch; the 1-D kernels of
-// srk_wgrad.hip measured slightly better WITH them).
+// built without SLP vectorisation: the compiler must not pair scalar fp32 operations into v_pk_*_f32 on its own (the pairs it
+// finds need register moves to line up: 657 -> 638 us on the dense-block batch with them off in the tile-owner form; the 1-D
+// kernels of srk_wgrad.hip measured slightly better WITH them).  The row-owner form writes its packed instructions by hand.
 #include "srk_wgrad_internal.h"
 
 using namespace srkw;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -30,7 +31,10 @@ constexpr int W22_THREADS = 256;
 #define W22_XG 5
 #endif
 #ifndef W22_NPS
-#define W22_NPS 1        // row-owner form: DMA pieces per vector-ALU gap (1: a tile's 20 pieces per wave ride on ten k-steps; 2: on five)
+#define W22_NPS 1        // row-owner form: DMA piece pairs per k-step (1: a tile's 20 pieces per wave ride on ten k-steps; 2: on five)
+#endif
+#ifndef W22_RG
+#define W22_RG 7         // row-owner form: the MFMA gap of a k-step that holds ALL its vector-ALU work (raw reads: gaps 0-5)
 #endif
 
 #ifdef SRK_STAMP      // diagnostic build (make stamp; tools/stamp_w22.py): per-workgroup phase stamps.  Only OUTSIDE the tile loop: a chained node
@@ -333,8 +337,9 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
   // positions = the same 16 accumulator tiles), instead of all 16 positions of one 32 x 32 tile.  A row of U = A g A^T and of
   // V = B^T d B needs only ONE combination of two raw rows (row pass first: t_j = d[ra][j] + s d[rb][j], with (ra, rb, s) wave-
   // uniform -- two LDS base offsets and one scalar coefficient, so the four waves run the SAME code), then the four column
-  // combinations: 4 + 4 VALU per cin tile, 2 + 2 per cout tile = 24 per 16 MFMAs instead of 36-44, for 24 instead of 12-20 LDS
-  // dwords (free beside fp32 MFMAs, which vector-ALU work is not).  The rows meet in G^T M G at the end, through the LDS.
+  // combinations: 4 + 4 operations per cin tile, 2 + 2 per cout tile = 24 per 16 MFMAs instead of 36-44 -- as 12 PACKED instructions
+  // (below) -- for 24 instead of 12-20 LDS dwords (free beside fp32 MFMAs, which vector-ALU work is not).  The rows meet in
+  // G^T M G at the end, through the LDS.
   //   B^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3);  A rows: (g0, g0 + g1, g0 - g1, g1)
   const int xra = wv == 0 ? 0 : (wv == 2 ? 2 : 1);
   const int xrb = wv == 0 ? 2 : (wv == 1 ? 2 : (wv == 2 ? 1 : 3));
@@ -350,8 +355,15 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
   asm volatile("" : "+v"(aoffA1), "+v"(aoffB1));
   const int boffA = W22_TP * 64 + (2 * hl) * 64 + l32 + xra * W22_IW * 64, boffB = W22_TP * 64 + (2 * hl) * 64 + l32 + xrb * W22_IW * 64;
   float bs0 = 0.f, bs1 = 0.f;
-  // operands: U[4 m + q] (cout tile m), V[4 n + q] (cin tile n); raw values gA/gB[2 m + j], dA/dB[4 n + j]
-  float U0[8], V0[8], U1[8], V1[8], gA[4], gB[4], dA[8], dB[8];
+  // The transform runs on PACKED fp32 instructions (tools/ubench/pk_beside_mfma.hip: beside fp32 MFMAs a v_pk_add_f32 / v_pk_fma_f32
+  // costs what a v_add_f32 does, so two results per instruction halve the bill): the pairs are the two pixels j, j + 1 that one
+  // ds_read2st64_b32 delivers into an aligned register pair; op_sel / neg modifiers do the broadcasts and signs of the column pass.
+  // Plain (non-volatile) asm: no chain, so the selector keeps the source order of the builtin MFMAs.
+  //   operands: U[4 m + q] (cout tile m), V[4 n + q] (cin tile n); raw pairs gA/gB[m] = rows ra / rb, pixels (0, 1); dA/dB[2 n + h] =
+  //   rows ra / rb, pixels (2 h, 2 h + 1)
+  float U0[8], V0[8], U1[8], V1[8];
+  f32x2 gA[2], gB[2], dA[4], dB[4];
+  const f32x2 xs2 = {xs, xs}, dsc2 = {dsc, dsc};
   auto rd_g = [&](int bb, int kk) {
     const int pr = kk & 3, cp = kk >> 2;
     const int o = bb * W22_TILE_FLOATS + ((2 * pr) * 16 + 4 * cp) * 64;
@@ -359,35 +371,37 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        gA[2 * m + j] = smem[(m ? aoffA1 : aoffA) + o + 64 * j];
-        gB[2 * m + j] = smem[(m ? aoffB1 : aoffB) + o + 64 * j];
+        gA[m][j] = smem[(m ? aoffA1 : aoffA) + o + 64 * j];
+        gB[m][j] = smem[(m ? aoffB1 : aoffB) + o + 64 * j];
       }
   };
   auto rd_d = [&](int bb, int kk, int n, bool second) {
     const int pr = kk & 3, cp = kk >> 2;
     const float* q = smem + bb * W22_TILE_FLOATS + (second ? boffB : boffA) + ((2 * pr) * W22_IW + 4 * cp) * 64 + 32 * n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) (second ? dB : dA)[4 * n + j] = q[64 * j];
+    for (int j = 0; j < 4; ++j) (second ? dB : dA)[2 * n + (j >> 1)][j & 1] = q[64 * j];
   };
-  auto xf_u = [&](float (&U)[8], bool count_bias) {                // 8 VALU + 2 (bias: row 1, position 1 IS the patch sum)
+  auto xf_u = [&](float (&U)[8], bool count_bias) {                // 2 packed + 1 (bias: row 1, position 1 IS the patch sum) per cout tile
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      U[4 * m + 0] = __builtin_fmaf(dsc, gB[2 * m + 0], gA[2 * m + 0]);
-      U[4 * m + 3] = __builtin_fmaf(dsc, gB[2 * m + 1], gA[2 * m + 1]);
-      U[4 * m + 1] = U[4 * m + 0] + U[4 * m + 3];
-      U[4 * m + 2] = U[4 * m + 0] - U[4 * m + 3];
+      f32x2 t, u12;
+      asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(dsc2), "v"(gB[m]), "v"(gA[m]));                    // (t0, t1) = gA + s gB
+      asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(u12) : "v"(t));      // (t0 + t1, t0 - t1)
+      U[4 * m + 0] = t[0]; U[4 * m + 1] = u12[0]; U[4 * m + 2] = u12[1]; U[4 * m + 3] = t[1];
     }
     bs0 += count_bias ? U[1] : 0.f;
     bs1 += count_bias ? U[5] : 0.f;
   };
-  float tt[8];
-  auto xf_vrow = [&](int n) {                                      // 4 VALU
+  f32x2 tt[4];
+  auto xf_vrow = [&](int n) {                                      // 2 packed: t_j = dA_j + s dB_j
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tt[4 * n + j] = __builtin_fmaf(xs, dB[4 * n + j], dA[4 * n + j]);
+    for (int h = 0; h < 2; ++h) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tt[2 * n + h]) : "v"(xs2), "v"(dB[2 * n + h]), "v"(dA[2 * n + h]));
   };
-  auto xf_vcol = [&](float (&V)[8], int n) {                       // 4 VALU
-    V[4 * n + 0] = tt[4 * n + 0] - tt[4 * n + 2]; V[4 * n + 1] = tt[4 * n + 1] + tt[4 * n + 2];
-    V[4 * n + 2] = tt[4 * n + 2] - tt[4 * n + 1]; V[4 * n + 3] = tt[4 * n + 1] - tt[4 * n + 3];
+  auto xf_vcol = [&](float (&V)[8], int n) {                       // 2 packed: (t0 - t2, t1 + t2), (t2 - t1, t1 - t3)
+    f32x2 v01, v23;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(tt[2 * n]), "v"(tt[2 * n + 1]));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(tt[2 * n + 1]), "v"(tt[2 * n]));
+    V[4 * n + 0] = v01[0]; V[4 * n + 1] = v01[1]; V[4 * n + 2] = v23[0]; V[4 * n + 3] = v23[1];
   };
   TilePos pos2;
   TileCtx c2;
@@ -405,18 +419,14 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
       if (i == 5) rd_d(nb, nk, 1, true);
 #endif
       if (mk == 1 && i == 3) { pos_step(pos2, mk_go); ctx_offsets(pos2, c2); ctx_rsrcs(pos2, c2); }
+      // ONE vector-ALU gap per k-step: the whole transform (12 packed + 2 scalar instructions) and both DMA pieces' offset selects
 #ifndef W22_NO_XFORM
-      if (i == W22_XS0) { xf_u(UN, next_real); xf_vrow(0); }
-      if (i == W22_XS1) { xf_vcol(VN, 0); xf_vrow(1); xf_vcol(VN, 1); }
+      if (i == W22_RG) { xf_u(UN, next_real); xf_vrow(0); xf_vcol(VN, 0); xf_vrow(1); xf_vcol(VN, 1); }
 #endif
 #ifndef W22_NO_DMA
-      if (dj >= 0 && dj < NPW / (2 * W22_NPS) && i == W22_XS0) {
+      if (dj >= 0 && dj < NPW / (2 * W22_NPS) && i == W22_RG) {
 #pragma unroll
-        for (int u = 0; u < W22_NPS; ++u) piece(dc, db, 2 * W22_NPS * dj + u, dlive);
-      }
-      if (dj >= 0 && dj < NPW / (2 * W22_NPS) && i == W22_XS1) {
-#pragma unroll
-        for (int u = 0; u < W22_NPS; ++u) piece(dc, db, 2 * W22_NPS * dj + W22_NPS + u, dlive);
+        for (int u = 0; u < 2 * W22_NPS; ++u) piece(dc, db, 2 * W22_NPS * dj + u, dlive);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);

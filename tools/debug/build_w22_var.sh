@@ -3,8 +3,8 @@
 set -e
 C=super-resolution_amd/csrc; name=$1; shift
 mkdir -p $C/build_var
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Iinclude -I$C -Xclang -target-feature -Xclang -packed-fp32-ops "$@" \
-  -c $C/srk_wgrad_w22.hip -o $C/build_var/w22_$name.o 2> >(grep -v "is not a recognized feature" >&2)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Iinclude -I$C -fno-slp-vectorize "$@" \
+  -c $C/srk_wgrad_w22.hip -o $C/build_var/w22_$name.o
 objs=$(ls $C/build/*.o | grep -v srk_wgrad_w22.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/build_var/libsrk_wg_$name.so $objs $C/build_var/w22_$name.o
 echo built $C/build_var/libsrk_wg_$name.so
