@@ -187,11 +187,35 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(va), "v"(vb));
   };
 
-  float Vc[6], Vn[6];
+  // Transformed operands of a GROUP (channel pair, M tile): VV[c] = column position c of (first, second) channel of the pair.  The
+  // transform runs on PACKED fp32 instructions, both channels of the pair at once (tools/ubench/pk_beside_mfma.hip: beside fp32 MFMAs a
+  // v_pk_fma_f32 costs what a v_fma_f32 does): 18 instructions per group instead of 18 per phase, and only every second phase has a
+  // vector-ALU gap at all.  The raw pairs arrive as ds_read_b64 = aligned register pairs already; constants ride in SGPR pairs.
+  f32x2 VVa[6], VVb[6];
   f32x2 ra[6], rb[6];                // raw pixels of the current group: rows a / b of this wave's row position, a channel pair each
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using IN = std::integral_constant<int, -1>;
   using Yes = std::true_type; using No = std::false_type;
+
+  // Input transform of a group: row combination d = ra + sgn rb, then B^T d of F(4,3) in 12 operations
+  // (4, 0, -5, 0, 1, 0 | 0, -4, -4, 1, 1, 0 | 0, 4, -4, -1, 1, 0 | 0, -2, -1, 2, 1, 0 | 0, 2, -1, -2, 1, 0 | 0, 4, 0, -5, 0, 1): 18 packed
+  // instructions for BOTH channels of the pair (the same fused operations, in the same order, as the scalar form: same bits).
+  const f32x2 sgn2 = {sgn, sgn};
+  auto xform6 = [&](f32x2 (&VN)[6]) {
+    const f32x2 kM4 = {-4.f, -4.f}, k4 = {4.f, 4.f}, kM5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, kM2 = {-2.f, -2.f};
+    f32x2 d[6], t1, t2, t3, t4, u0, u5;
+#define W42_PKFMA(r, k, a, b) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(k), "v"(a), "v"(b))
+#define W42_PKADD(r, a, b) asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
+#define W42_PKSUB(r, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b))
+#pragma unroll
+    for (int j = 0; j < 6; ++j) W42_PKFMA(d[j], sgn2, rb[j], ra[j]);
+    W42_PKFMA(t1, kM4, d[2], d[4]); W42_PKFMA(t2, kM4, d[1], d[3]);
+    W42_PKSUB(t3, d[4], d[2]); W42_PKSUB(t4, d[3], d[1]);
+    W42_PKFMA(u0, kM5, d[2], d[4]); W42_PKFMA(VN[0], k4, d[0], u0);
+    W42_PKADD(VN[1], t1, t2); W42_PKSUB(VN[2], t1, t2);
+    W42_PKFMA(VN[3], k2, t4, t3); W42_PKFMA(VN[4], kM2, t4, t3);
+    W42_PKFMA(u5, kM5, d[3], d[5]); W42_PKFMA(VN[5], k4, d[1], u5);
+  };
 
   // One phase = 12 MFMAs of (channel E of the k-halves, M tile MT) on V / B.  The phases of a chunk come in four GROUPS
   // (channel pair, M tile): the raw pixels of a group are read ONCE as channel pairs (ds_read_b64: half the LDS instructions of
@@ -203,20 +227,19 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   //   every slot  (LB) one weight load (dwordx2: a channel pair) of pair lp of chunk lq into BN
   //   slot 11     (DJ >= 0) halo piece DJ of chunk dq into buffer DB: one gather per phase, so that a piece never queues behind
   //               the previous one in the address unit (five in a row cost ~180 cycles each)
-  auto phase = [&](auto mtc, auto ec, const float (&V)[6], const f32x2 (&B)[6][2], auto secondc, auto nbc, auto nmtc, auto npc,
-                   float (&VN)[6], auto lbc, int lq, int lp, f32x2 (&BN)[6][2], auto djc, int dq, auto dbc) {
+  auto phase = [&](auto mtc, auto ec, const f32x2 (&V)[6], const f32x2 (&B)[6][2], auto secondc, auto nbc, auto nmtc, auto npc,
+                   f32x2 (&VN)[6], auto lbc, int lq, int lp, f32x2 (&BN)[6][2], auto djc, int dq, auto dbc) {
     constexpr int MT = decltype(mtc)::value, E = decltype(ec)::value & 1;
     constexpr bool SECOND = decltype(secondc)::value;
     constexpr int off = (decltype(nbc)::value * BUF4 + decltype(nmtc)::value * 296) * 4 + 2 * decltype(npc)::value;
     constexpr bool LB = decltype(lbc)::value;
     constexpr int DJ = decltype(djc)::value, DB = decltype(dbc)::value;
-    constexpr int X0 = SECOND ? 6 : 0, COMP = SECOND ? 0 : 1;       // transform: first slot, channel of the pair
+    constexpr int X0 = 6;                                           // transform (second phase of a group only): first slot
     const unsigned so = (unsigned)(2 * lq + lp) * sB_ep + (unsigned)wv * 6u * sB_c;
-    float d0, d1, d2, d3, d4, d5, t1, t2, t3, t4;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int c = i >> 1, nh = i & 1;
-      mfma((NMT * nh + MT) * 6 + c, V[c], B[c][nh][E]);
+      mfma((NMT * nh + MT) * 6 + c, V[c][E], B[c][nh][E]);
 #ifndef W42_NO_LB      // (-DW42_NO_LB / -DW42_NO_DMA: timing-only ablation builds of tools/debug/run_var.sh -- wrong results)
       if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
 #endif
@@ -233,17 +256,10 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
       // within a wave (tools/ubench/lds_beside_mfma.hip) and every gap that holds any VALU pays a fixed restart on top.  Pure
       // arithmetic floats freely between the (volatile) MFMAs when instructions are selected, so the inputs pass through an
       // empty volatile asm at the head of the gap and the results through one at its end.
-      if (i == X0 + W42_XA) {
+      if (SECOND && i == X0 + W42_XA) {
         asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]),
                           "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]));
-        d0 = ra[0][COMP] + sgn * rb[0][COMP]; d1 = ra[1][COMP] + sgn * rb[1][COMP]; d2 = ra[2][COMP] + sgn * rb[2][COMP];
-        d3 = ra[3][COMP] + sgn * rb[3][COMP]; d4 = ra[4][COMP] + sgn * rb[4][COMP]; d5 = ra[5][COMP] + sgn * rb[5][COMP];
-        // B^T d of F(4,3) in 12 instructions: (4, 0, -5, 0, 1, 0 | 0, -4, -4, 1, 1, 0 | 0, 4, -4, -1, 1, 0 | 0, -2, -1, 2, 1, 0 | 0, 2, -1, -2, 1, 0 | 0, 4, 0, -5, 0, 1)
-        t1 = __builtin_fmaf(-4.f, d2, d4); t2 = __builtin_fmaf(-4.f, d1, d3); t3 = d4 - d2; t4 = d3 - d1;
-        VN[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-        VN[1] = t1 + t2; VN[2] = t1 - t2;
-        VN[3] = __builtin_fmaf(2.f, t4, t3); VN[4] = __builtin_fmaf(-2.f, t4, t3);
-        VN[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+        xform6(VN);
         asm volatile("" : "+v"(VN[0]), "+v"(VN[1]), "+v"(VN[2]), "+v"(VN[3]), "+v"(VN[4]), "+v"(VN[5]));
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -270,32 +286,32 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     using Bc = std::integral_constant<int, b>; using Bn = std::integral_constant<int, b ^ 1>;
     if constexpr (NMT == 1) {
       // one M tile: (e) = (0) (1) | (2) | barrier | (3); pieces 1, 2 of chunk q + 1 behind (0), (1); piece 0 of chunk q + 2 behind (3)
-      phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
-      phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
-      phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});
+      phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
+      phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I0{}, I1{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
+      phase(I0{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});
       W42_WAIT_PIECES();
       __syncthreads();
-      phase(I0{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
+      phase(I0{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
     } else {
-    phase(I0{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
+    phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
     W42_SEG(0);
-    phase(I0{}, I1{}, Vn, P0, Yes{}, Bc{}, I1{}, I0{}, Vc, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
+    phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I1{}, I0{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
     W42_SEG(1);
-    phase(I1{}, I0{}, Vc, P0, No{}, Bc{}, I0{}, I0{}, Vn, No{}, 0, 0, P1, I3{}, q + 1, Bn{});
+    phase(I1{}, I0{}, VVb, P0, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P1, I3{}, q + 1, Bn{});
     W42_SEG(2);
-    phase(I1{}, I1{}, Vn, P0, Yes{}, Bc{}, I0{}, I1{}, Vc, No{}, 0, 0, P1, I4{}, q + 1, Bn{});
+    phase(I1{}, I1{}, VVb, P0, Yes{}, Bc{}, I0{}, I1{}, VVa, No{}, 0, 0, P1, I4{}, q + 1, Bn{});
     W42_SEG(3);
-    phase(I0{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (behind the last chunk: pair 0 of chunk nq is fetched from the padding srk_packed_floats_wino42 reserves and never used)
+    phase(I0{}, I2{}, VVa, P1, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (behind the last chunk: pair 0 of chunk nq is fetched from the padding srk_packed_floats_wino42 reserves and never used)
     W42_SEG(4);
-    phase(I0{}, I3{}, Vn, P1, Yes{}, Bc{}, I1{}, I1{}, Vc, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    phase(I0{}, I3{}, VVa, P1, Yes{}, Bc{}, I1{}, I1{}, VVb, No{}, 0, 0, P0, IN{}, 0, Bc{});
     W42_SEG(5);
-    phase(I1{}, I2{}, Vc, P1, No{}, Bc{}, I0{}, I0{}, Vn, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    phase(I1{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, IN{}, 0, Bc{});
     W42_SEG(6);
     // vector-memory operations retire in order: all but the 12 weight loads of (2,0) = every DMA piece of chunk q + 1
     W42_WAIT_PIECES();
     __syncthreads();
     W42_SEG(7);
-    phase(I1{}, I3{}, Vn, P1, Yes{}, Bn{}, I0{}, I0{}, Vc, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)
+    phase(I1{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)
     W42_SEG(8);
     }
   };
@@ -324,16 +340,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   }
   W42_STAMP(2);
   {
-    float d[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       ra[j] = *reinterpret_cast<const f32x2*>(ldsA + 4 * j);
       rb[j] = *reinterpret_cast<const f32x2*>(ldsB + 4 * j);
-      d[j] = ra[j][0] + sgn * rb[j][0];
     }
-    const float t1 = __builtin_fmaf(-4.f, d[2], d[4]), t2 = __builtin_fmaf(-4.f, d[1], d[3]), t3 = d[4] - d[2], t4 = d[3] - d[1];   // (as in phase())
-    Vc[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4])); Vc[1] = t1 + t2; Vc[2] = t1 - t2;
-    Vc[3] = __builtin_fmaf(2.f, t4, t3); Vc[4] = __builtin_fmaf(-2.f, t4, t3); Vc[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+    xform6(VVa);
   }
   piece(1, 1, I0{});           // (the state every chunk starts in: piece 0 of the next chunk in flight)
   W42_SEG_RESET();
