@@ -15,7 +15,8 @@
 //     all L2 hits) and never staged in LDS; only the 34 x 18 raw halo (20 KB per 8-channel chunk, 5 DMA pieces per wave) is,
 //   * the four row positions of a patch meet only once, after the K loop, through LDS (y0 / y1 above), which also re-deals the
 //     tiles so that every wave ends with the register layout conv_epilogue expects.
-// Per 8-channel chunk and wave: 96 MFMAs, 160 VALU (transform), 48 ds_read_b64, 24 buffer_load_dwordx2, 5 DMA pieces, 1 barrier.
+// Per 8-channel chunk and wave: 96 MFMAs, 72 packed VALU (transform: 18 per channel pair and M tile), 48 ds_read_b64, 24 buffer_load_dwordx2,
+// 5 DMA pieces, 1 barrier.
 #include "srk_internal.h"
 #include "srk_epilogue.h"
 #include "srk_chain.h"
@@ -38,7 +39,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define W42_STORE_AUX 0          // cache-policy bits of the one-conv kernels' 16-byte stores (A/B builds: 2 = nt, 16 = sc1)
 #endif
 #ifndef W42_XA
-#define W42_XA 2         // the gap (relative to the first transform slot of a phase) that holds the input transform
+#define W42_XA 2         // the gap (relative to slot 6 of a group's second phase) that holds the input transform
 #endif
 #ifdef SRK_STAMP
 __device__ unsigned long long* g_w42_stamps = nullptr;
@@ -221,9 +222,9 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   // (channel pair, M tile): the raw pixels of a group are read ONCE as channel pairs (ds_read_b64: half the LDS instructions of
   // dword reads and a 2-way instead of a 4-way bank conflict -- with dword reads the LDS cost 13 cycles of issue each, 1300 per
   // chunk).  In the shadow of the MFMAs, placed by hand (one sched_barrier per MFMA):
-  //   first phase of a group   slots 0-5: row combination + F(4,3) column transform of the pair's SECOND channel into VN
-  //   second phase of a group  slots 0-5: the NEXT group's raw reads (buffer NB, M tile NMT, pair NP; two ds_read_b64 each),
-  //                            slots 6-11: its first channel's transform into VN
+  //   first phase of a group   no vector-ALU work at all (MFMAs on the pair's first channel, V[.][0])
+  //   second phase of a group  (MFMAs on V[.][1]) slots 0-5: the NEXT group's raw reads (buffer NB, M tile NMT, pair NP; two
+  //                            ds_read_b64 each), slot 6 + W42_XA: its packed transform (xform6: both channels) into VN
   //   every slot  (LB) one weight load (dwordx2: a channel pair) of pair lp of chunk lq into BN
   //   slot 11     (DJ >= 0) halo piece DJ of chunk dq into buffer DB: one gather per phase, so that a piece never queues behind
   //               the previous one in the address unit (five in a row cost ~180 cycles each)
