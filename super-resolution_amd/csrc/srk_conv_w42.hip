@@ -38,6 +38,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef W42_STORE_AUX
 #define W42_STORE_AUX 0          // cache-policy bits of the one-conv kernels' 16-byte stores (A/B builds: 2 = nt, 16 = sc1)
 #endif
+#ifndef W42_LDSW
+#define W42_LDSW 2       // the transformed weights reach the MFMAs 0: global -> registers, four phases ahead (rounds 2-3); 1: through the LDS (DMA three
+#endif                   // channel pairs ahead into a ring behind the halo buffers); 2: through the LDS in the 16-row form only.  Same-box A/B of a dense
+                         // block (tools/debug/ab_w42_ldsw.sh): 32-row form 445 (registers) vs 452 us (ring); 16-row form 276 vs 272 us.  The ring
+                         // was built to test whether the weight loads cost LATENCY (the timing-only build without them runs 5 % / 19 %
+                         // faster): they do not -- with every load three pairs (3-4 us) ahead and no vmcnt wait on a weight left, nothing changes.
 #ifndef W42_XA
 #define W42_XA 2         // the gap (relative to slot 6 of a group's second phase) that holds the input transform
 #endif
@@ -76,7 +82,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   constexpr int BUF4 = 2 * HS4;                     // 1280 float4 = 20 KB (NMT 2) / 768 = 12 KB (NMT 1) per chunk
   constexpr int NPC = BUF4 / 256;                   // DMA pieces per wave and chunk: 5 / 3
   constexpr int EXSLOTS = 16 * NMT;                 // 4 KB slots of the exchange area (64 KB per M tile)
-  constexpr int SMEM4 = (EXSLOTS + 4) * 256;        // 144 KB / 80 KB: exchange + 4 x 4 KB epilogue scratch (>= 2 halo buffers)
+  // weight ring (W42_LDSW): behind the two halo buffers, per wave 4 slots of 6 KB = one (chunk, channel pair) of this wave's row position:
+  // [c][k-half][64 output channels] float2 -- 96 KB.  NMT 2: inside the exchange area (idle during the K loop); NMT 1: the area grows to 120 KB.
+  constexpr int WRING4 = 2 * BUF4, WSLOT4 = 384, WWAVE4 = 4 * WSLOT4;
+  constexpr int SMEM4_EX = (EXSLOTS + 4) * 256;     // 144 KB / 80 KB: exchange + 4 x 4 KB epilogue scratch (>= 2 halo buffers)
+  constexpr bool LDSW = W42_LDSW == 1 || (W42_LDSW == 2 && NMT == 1);
+  constexpr int SMEM4 = (LDSW && WRING4 + 4 * WWAVE4 > SMEM4_EX) ? WRING4 + 4 * WWAVE4 : SMEM4_EX;
   __shared__ float4 smem[SMEM4];
 
   int tid_ = threadIdx.x;
@@ -122,13 +133,35 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   f32x2 (&P0)[6][2] = *[&]() { if constexpr (PF) return carryP0; else return &P0own; }();
   const bool fresh_start = !PF || c == 0;          // (PF, c > 0: the previous link has issued this conv's first weights and halo chunk)
   // the first weights need nothing but the lane id: they are on their way before the halo address arithmetic starts
+  static_assert(!(PF && LDSW), "the prefetch across chain links fetches weights into registers");
+  // W42_LDSW: DMA instruction cc of pair s (= 2 q + lp) copies rows (cc, k-half 0 / 1) of this wave's block -- 2 x 512 B of the 64 output
+  // channels n0.. -- into ring slot s & 3; a lane reads its B operand (cc, nh) back as one ds_read_b64.  Pairs past the last chunk fall out
+  // of the descriptor's range (zeros land in a slot nobody reads).
+  const unsigned wvo = (unsigned)(((lane >> 5) * CoutP + n0) * 8 + (lane & 31) * 16);
+  const float* wlds = reinterpret_cast<const float*>(smem + WRING4 + wv * WWAVE4) + hl * 128 + l32 * 2;
+  auto wpiece = [&](int s_, auto slotc, int cc) {
+    constexpr int SL = decltype(slotc)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + WRING4 + wv * WWAVE4 + SL * WSLOT4 + cc * 64), 16,
+                                             wvo, (unsigned)s_ * sB_ep + (unsigned)wv * 6u * sB_c + (unsigned)cc * sB_c, 0, 0);
+  };
   if (fresh_start) {
-    const unsigned so = (unsigned)wv * 6u * sB_c;
+    if constexpr (LDSW) {
 #pragma unroll
-    for (int cc = 0; cc < 6; ++cc)
+      for (int cc = 0; cc < 6; ++cc) wpiece(0, std::integral_constant<int, 0>{}, cc);
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
-        P0[cc][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + cc * sB_c, 0));
+      for (int cc = 0; cc < 6; ++cc) wpiece(1, std::integral_constant<int, 1>{}, cc);
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) wpiece(2, std::integral_constant<int, 2>{}, cc);
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) wpiece(3, std::integral_constant<int, 3>{}, cc);
+    } else {
+      const unsigned so = (unsigned)wv * 6u * sB_c;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          P0[cc][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + cc * sB_c, 0));
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   unsigned vo[NPC];
@@ -229,7 +262,8 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   //   slot 11     (DJ >= 0) halo piece DJ of chunk dq into buffer DB: one gather per phase, so that a piece never queues behind
   //               the previous one in the address unit (five in a row cost ~180 cycles each)
   auto phase = [&](auto mtc, auto ec, const f32x2 (&V)[6], const f32x2 (&B)[6][2], auto secondc, auto nbc, auto nmtc, auto npc,
-                   f32x2 (&VN)[6], auto lbc, int lq, int lp, f32x2 (&BN)[6][2], auto djc, int dq, auto dbc) {
+                   f32x2 (&VN)[6], auto lbc, int lq, int lp, f32x2 (&BN)[6][2], auto djc, int dq, auto dbc,
+                   auto lsc, auto wsc, int ws) {
     constexpr int MT = decltype(mtc)::value, E = decltype(ec)::value & 1;
     constexpr bool SECOND = decltype(secondc)::value;
     constexpr int off = (decltype(nbc)::value * BUF4 + decltype(nmtc)::value * 296) * 4 + 2 * decltype(npc)::value;
@@ -242,7 +276,13 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
       const int c = i >> 1, nh = i & 1;
       mfma((NMT * nh + MT) * 6 + c, V[c][E], B[c][nh][E]);
 #ifndef W42_NO_LB      // (-DW42_NO_LB / -DW42_NO_DMA: timing-only ablation builds of tools/debug/run_var.sh -- wrong results)
-      if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
+      if constexpr (LDSW) {
+        if (LB) BN[c][nh] = *reinterpret_cast<const f32x2*>(wlds + decltype(lsc)::value * (WSLOT4 * 4) + c * 256 + nh * 64);
+        constexpr int WS = decltype(wsc)::value;
+        if (WS >= 0 && i < 6) wpiece(ws, std::integral_constant<int, (WS >= 0 ? WS : 0)>{}, i);
+      } else {
+        if (LB) BN[c][nh] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, vB + nh * 256, so + c * sB_c, 0));
+      }
 #endif
 #ifndef W42_NO_DMA
       // (behind the phase's weight loads: vector memory retires in order, and issued in the transform gap, ahead of them, the
@@ -271,11 +311,25 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   // has issued exactly the weight loads of ONE phase (6 column positions x 2 channel halves, the LB phase (2,0) resp. (2)), so
   // "all but the W42_LB_PER_PHASE youngest" = every DMA piece of the next chunk has landed.  The literal in the asm below is this
   // constant (static_assert), and tools/check_w42_hazards.py checks the same statement in the disassembly of the shipped object.
-  constexpr int W42_LB_PER_PHASE = 6 * 2;
-  static_assert(W42_LB_PER_PHASE == 12, "the s_waitcnt vmcnt(12) in front of the stage barrier counts one phase of weight loads");
-#define W42_STR2(x) #x
-#define W42_STR(x) W42_STR2(x)
-#define W42_WAIT_PIECES() asm volatile("s_waitcnt vmcnt(" W42_STR(12) ")" ::: "memory")
+  // W42_LDSW: behind the last halo piece of chunk q + 1 a wave has issued exactly the SIX weight DMA instructions of pair 2 q + 5 (phase
+  // (3,0) resp. (2)): "all but the 6 youngest".  Everything a phase reads from the weight ring was issued before those pieces, i.e. has
+  // landed by the PREVIOUS chunk's wait at the latest -- the weights need no wait of their own.
+  constexpr int W42_LB_PER_PHASE = LDSW ? 6 : 6 * 2;
+  // LDSW: a BARE barrier.  __syncthreads() carries a workgroup-scope fence, and with LDS-DMA instructions in flight (the weight ring's
+  // six youngest) the compiler satisfies that fence with s_waitcnt vmcnt(0): the stage would wait for weights it needs two chunks later.
+  // What the barrier orders here is LDS traffic of one CU, which the counted wait + s_barrier order by themselves; the empty asm
+  // statements keep the compiler from moving LDS reads across it.
+  static_assert(W42_LB_PER_PHASE == (LDSW ? 6 : 12), "the literals of the s_waitcnt vmcnt(6 | 12) in front of the stage barrier");
+  auto stage_wait_and_barrier = [&]() {
+    if constexpr (LDSW) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      __syncthreads();
+    }
+  };
   W42_SEG_BEGIN();
   // Chunk q sits in buffer b:  (e, mt) = (0,0) (1,0) | (0,1) (1,1) | (2,0) (3,0) | (2,1) | barrier | (3,1)
   //   weights: P1 <- pair 1 of chunk q during (0,0), P0 <- pair 0 of chunk q + 1 during (2,0): four phases ahead of their use
@@ -285,34 +339,35 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   auto chunk = [&](int q, auto bc) {
     constexpr int b = decltype(bc)::value;
     using Bc = std::integral_constant<int, b>; using Bn = std::integral_constant<int, b ^ 1>;
+    // weight ring slots (pair s lives in slot s & 3, and 2 q & 3 = 2 b): P1 <- pair 2 q + 1, P0 <- pair 2 q + 2; filled: pairs 2 q + 4, 2 q + 5
+    using S1 = std::integral_constant<int, 2 * b + 1>; using S2 = std::integral_constant<int, (2 * b + 2) & 3>;
+    using F0 = std::integral_constant<int, 2 * b>; using F1 = std::integral_constant<int, 2 * b + 1>;
     if constexpr (NMT == 1) {
       // one M tile: (e) = (0) (1) | (2) | barrier | (3); pieces 1, 2 of chunk q + 1 behind (0), (1); piece 0 of chunk q + 2 behind (3)
-      phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
-      phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I0{}, I1{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
-      phase(I0{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});
-      W42_WAIT_PIECES();
-      __syncthreads();
-      phase(I0{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{});
+      phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{}, S1{}, IN{}, 0);
+      phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I0{}, I1{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{}, I0{}, F0{}, 2 * q + 4);
+      phase(I0{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{}, S2{}, F1{}, 2 * q + 5);
+      stage_wait_and_barrier();
+      phase(I0{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{}, I0{}, IN{}, 0);
     } else {
-    phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{});
+    phase(I0{}, I0{}, VVa, P0, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q, 1, P1, I1{}, q + 1, Bn{}, S1{}, IN{}, 0);
     W42_SEG(0);
-    phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I1{}, I0{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{});
+    phase(I0{}, I1{}, VVa, P0, Yes{}, Bc{}, I1{}, I0{}, VVb, No{}, 0, 0, P1, I2{}, q + 1, Bn{}, I0{}, F0{}, 2 * q + 4);
     W42_SEG(1);
-    phase(I1{}, I0{}, VVb, P0, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P1, I3{}, q + 1, Bn{});
+    phase(I1{}, I0{}, VVb, P0, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P1, I3{}, q + 1, Bn{}, I0{}, IN{}, 0);
     W42_SEG(2);
-    phase(I1{}, I1{}, VVb, P0, Yes{}, Bc{}, I0{}, I1{}, VVa, No{}, 0, 0, P1, I4{}, q + 1, Bn{});
+    phase(I1{}, I1{}, VVb, P0, Yes{}, Bc{}, I0{}, I1{}, VVa, No{}, 0, 0, P1, I4{}, q + 1, Bn{}, I0{}, IN{}, 0);
     W42_SEG(3);
-    phase(I0{}, I2{}, VVa, P1, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{});   // (behind the last chunk: pair 0 of chunk nq is fetched from the padding srk_packed_floats_wino42 reserves and never used)
+    phase(I0{}, I2{}, VVa, P1, No{}, Bc{}, I0{}, I0{}, VVb, Yes{}, q + 1, 0, P0, IN{}, 0, Bc{}, S2{}, IN{}, 0);   // (behind the last chunk: pair 0 of chunk nq is fetched from the padding srk_packed_floats_wino42 reserves and never used)
     W42_SEG(4);
-    phase(I0{}, I3{}, VVa, P1, Yes{}, Bc{}, I1{}, I1{}, VVb, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    phase(I0{}, I3{}, VVa, P1, Yes{}, Bc{}, I1{}, I1{}, VVb, No{}, 0, 0, P0, IN{}, 0, Bc{}, I0{}, F1{}, 2 * q + 5);
     W42_SEG(5);
-    phase(I1{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, IN{}, 0, Bc{});
+    phase(I1{}, I2{}, VVb, P1, No{}, Bc{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, IN{}, 0, Bc{}, I0{}, IN{}, 0);
     W42_SEG(6);
     // vector-memory operations retire in order: all but the 12 weight loads of (2,0) = every DMA piece of chunk q + 1
-    W42_WAIT_PIECES();
-    __syncthreads();
+    stage_wait_and_barrier();
     W42_SEG(7);
-    phase(I1{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{});   // (behind the last chunk: a V nobody uses, no branch)
+    phase(I1{}, I3{}, VVb, P1, Yes{}, Bn{}, I0{}, I0{}, VVa, No{}, 0, 0, P0, I0{}, q + 2, Bc{}, I0{}, IN{}, 0);   // (behind the last chunk: a V nobody uses, no branch)
     W42_SEG(8);
     }
   };
@@ -340,6 +395,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     __syncthreads();
   }
   W42_STAMP(2);
+  if constexpr (LDSW) {
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) P0[cc][nh] = *reinterpret_cast<const f32x2*>(wlds + cc * 256 + nh * 64);
+  }
   {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {

@@ -6,10 +6,12 @@ extracted with llvm-objdump --offloading and disassembled), so the flags checked
    between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB: no v_mfma in the wino42 kernels may read a register
    that one of the two preceding instructions wrote (VALU destinations only: loads are covered by s_waitcnt, which the compiler
    does insert for inline-asm operands).  The window is reset at branches and at symbols.
-2. The stage barrier's hand-written `s_waitcnt vmcnt(12)` encodes a count of vector-memory operations in flight: the 12 youngest
-   ones must be the weight loads of one phase (buffer_load_dwordx2), and the next older one a halo DMA piece (buffer_load ... lds)
-   -- i.e. "all but the 12 youngest" retires exactly every DMA piece of the next chunk.  A schedule edit that changes the count
-   fails here instead of racing on the GPU.
+2. The stage barrier's hand-written counted `s_waitcnt vmcnt(N)` encodes a count of vector-memory operations in flight.  Weights
+   through the LDS ring (W42_LDSW=1, the default): N = 6, the six youngest are the weight DMA instructions of one channel pair
+   (buffer_load_dwordx4 ... lds) and the next older one is the last halo piece of the next chunk.  Weights into registers
+   (W42_LDSW=0): N = 12 register loads of one phase (buffer_load_dwordx2) behind a halo DMA piece.  Either way "all but the N
+   youngest" retires exactly every DMA piece of the next chunk; a schedule edit that changes the count fails here instead of
+   racing on the GPU.  (The check cannot tell a weight DMA from a halo piece by its mnemonic: it relies on the count.)
 Exit status 1 on a violation.  Usage: python tools/check_w42_hazards.py [object file]"""
 import os, re, shutil, subprocess, sys, tempfile
 
@@ -83,11 +85,12 @@ def main():
             waits_checked += 1
             n = int(re.search(r"vmcnt\((\d+)\)", last_wait).group(1))
             young, older = vmem[-n:] if n else [], vmem[-n - 1:len(vmem) - n]
-            ok = len(young) == n and all(v.startswith("buffer_load_dwordx2") and " lds" not in v for v in young) and \
-                len(older) == 1 and " lds" in older[0]
+            regs_form = all(v.startswith("buffer_load_dwordx2") and " lds" not in v for v in young)          # W42_LDSW=0: 12 register loads
+            ring_form = n == 6 and all(v.startswith("buffer_load_dwordx4") and " lds" in v for v in young)      # W42_LDSW=1: 6 ring DMA instructions
+            ok = len(young) == n and (regs_form or ring_form) and len(older) == 1 and " lds" in older[0]
             if n and not ok:
                 bad += 1
-                print("VMCNT: `%s` + s_barrier does not sit behind [halo DMA piece, %d weight loads]; last vector-memory ops: %s"
+                print("VMCNT: `%s` + s_barrier does not sit behind [halo DMA piece, %d weight loads / ring DMA instructions]; last vector-memory ops: %s"
                       % (last_wait, n, [v.split()[0] + (" lds" if " lds" in v else "") for v in vmem[-n - 1:]]))
         # (counted, vmcnt only; a counted wait right behind a `vmcnt(0)` is the compiler's own, weaker, and means nothing)
         counted = re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", t) and not t.endswith("(0)") and prev_text != "s_waitcnt vmcnt(0)"
