@@ -135,13 +135,16 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   // the first weights need nothing but the lane id: they are on their way before the halo address arithmetic starts
   static_assert(!(PF && LDSW), "the prefetch across chain links fetches weights into registers");
   // W42_LDSW: DMA instruction cc of pair s (= 2 q + lp) copies rows (cc, k-half 0 / 1) of this wave's block -- 2 x 512 B of the 64 output
-  // channels n0.. -- into ring slot s & 3; a lane reads its B operand (cc, nh) back as one ds_read_b64.  Pairs past the last chunk fall out
-  // of the descriptor's range (zeros land in a slot nobody reads).
+  // channels n0.. -- into ring slot s & 3; a lane reads its B operand (cc, nh) back as one ds_read_b64.
   const unsigned wvo = (unsigned)(((lane >> 5) * CoutP + n0) * 8 + (lane & 31) * 16);
   const float* wlds = reinterpret_cast<const float*>(smem + WRING4 + wv * WWAVE4) + hl * 128 + l32 * 2;
   auto wpiece = [&](int s_, auto slotc, int cc) {
     constexpr int SL = decltype(slotc)::value;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + WRING4 + wv * WWAVE4 + SL * WSLOT4 + cc * 64), 16,
+    // pairs past the last chunk (the ring runs three pairs ahead) go out through a descriptor of ZERO records, like the halo pieces past
+    // the last chunk: the pair offset rides in the scalar offset, which the hardware's range check does not cover -- with the real
+    // descriptor they would read up to four pairs (98 KB at 64 output channels) behind the packed weights
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, s_ < 2 * nq ? wbytes : 0u, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(smem + WRING4 + wv * WWAVE4 + SL * WSLOT4 + cc * 64), 16,
                                              wvo, (unsigned)s_ * sB_ep + (unsigned)wv * 6u * sB_c + (unsigned)cc * sB_c, 0, 0);
   };
   if (fresh_start) {
