@@ -329,13 +329,15 @@ def test_transposed_conv_variants_keep_the_reference_state_dict(srk, golden_dir)
 def test_inline_asm_mfma_hazards_of_the_wino42_kernel():
     """The F(2x4,3x3) conv kernel issues its MFMAs as inline assembly (register classes spelled out), which the compiler's
     hazard recogniser does not see: the code of the SHIPPED object must keep two wait states between a VALU write and an MFMA
-    read, and its hand-counted `s_waitcnt vmcnt(12)` must sit behind exactly [halo DMA piece, 12 weight loads].  Checked in the four
-    one-conv kernels (864 MFMAs) and the two chain kernels, whose K loop exists twice (576)."""
+    read, and its hand-counted `s_waitcnt vmcnt(12 | 6)` must sit behind exactly [halo DMA piece, 12 weight loads | 6 ring DMA
+    instructions].  Checked in the four one-conv kernels (864 MFMAs) and the two chain kernels, whose K loop exists twice (576); the
+    2-D Winograd weight-gradient kernels (builtin MFMAs, but a packed transform in inline assembly) get the VALU -> MFMA check too."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_w42_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 violation(s)" in r.stdout and "1440 v_mfma" in r.stdout
+    assert "1024 v_mfma instructions in the wino22 kernels" in r.stdout and "violation(s)" in r.stdout and r.stdout.count(": 0 violation(s)") == 2
 
 
 def test_unknown_and_ignored_options_are_reported_once(capsys):
