@@ -34,7 +34,9 @@ typedef enum srk_status {
   SRK_ERR_UNSUPPORTED = -2,    /* combination of modes not implemented              */
   SRK_ERR_ALIGNMENT = -3,      /* view not 16-byte aligned where a vector path needs */
   SRK_ERR_WORKSPACE = -4,      /* workspace too small                                */
-  SRK_ERR_LAUNCH = -5          /* hipLaunchKernel reported an error                 */
+  SRK_ERR_LAUNCH = -5,         /* hipLaunchKernel reported an error                 */
+  SRK_ERR_CHAIN_TIMEOUT = -6   /* a chain launch (srk_conv3x3_seq) gave up: not resident within its bound, or a flag wait timed out.
+                                  Nothing was launched by THIS call; call srk_chain_recover(), then repeat the iteration */
 } srk_status;
 
 /* how the logical conv input is read from memory */
@@ -109,6 +111,9 @@ size_t srk_conv3x3_signs_bytes(const srk_conv_args* a);
 /* the same for a whole srk_conv3x3_seq call (bytes of ONE conv's buffer; every conv of the sequence needs the same); 0: this sequence's
  * launches offer no sign bits (the caller keeps passing the mask tensors) */
 size_t srk_conv3x3_seq_signs_bytes(const srk_conv_args* args, int n);
+/* layout tag of those bits (tile rows | wp_format << 8; 0: none).  The sequence that writes sign bits and the one that reads them may be
+ * dispatched to different kernel forms: use the bits only if both report the same tag, else pass the mask tensors. */
+int srk_conv3x3_seq_signs_tag(const srk_conv_args* args, int n);
 
 int srk_conv3x3(const srk_conv_args* a, void* stream);
 /* n of them launched back to back on `stream`, in array order, from ONE call: the five forward (or five data-gradient) convolutions of
@@ -122,13 +127,41 @@ int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
  * device-scope flags instead of a kernel boundary, and the next conv's first (old-slice) stage streams in beside the previous conv's
  * end.  Results: wp_format 6 bit-identical to the separate launches; 7 / 8 identical up to the order of the fp32 sums (one unit in the
  * last place of the 16-bit outputs).  At most one chain kernel is in flight per device (launches on different streams are ordered by
- * an event).  A flag wait that runs into its 30 s limit does not hang: the NEXT srk_conv3x3_seq call returns SRK_ERR_LAUNCH and the
- * forms are switched off.  SRK_H16_CHAIN=0 / SRK_W42_CHAIN=0 (srk_debug_set_h16_chain / _w42_chain(0)) disable them; for wp_format
- * 7 / 8 the default (1) uses the form where the 16-row kernel would run, 2 wherever the sequence is eligible.
+ * an event).
+ * SINGLE TENANT: a chain kernel needs all of its workgroups resident at once, i.e. the process has the GPU to itself (one process per
+ * GPU).  Every launch starts with a CENSUS: each workgroup counts itself in and waits -- at most SRK_CHAIN_ENTRY_MS, default 50 ms --
+ * until the whole grid has; if it has not (another process on the GPU, a kernel of another stream holding CUs for that long), every
+ * workgroup returns before anything is stored and before unpublished data is consumed.  A flag wait inside a launch is bounded too
+ * (30 s; behind a passed census it only trips on a fault).  Either way a host-visible fault word is set, and from then on
+ *   - srk_adam_count_step tells the optimizer step that follows to skip itself, ON THE DEVICE (no weight ever sees a gradient computed
+ *     from a launch that gave up, however far the host has run ahead),
+ *   - the next srk_conv3x3_seq / srk_adam_* call returns SRK_ERR_CHAIN_TIMEOUT and launches nothing,
+ * until srk_chain_recover(): it waits for the device, clears the fault and lets the chain forms rest (64, 512, 4096, ... sequence calls go
+ * conv by conv; then they are tried again).  The caller repeats the iteration (train.Stepper does).
+ * SRK_H16_CHAIN=0 / SRK_W42_CHAIN=0 (srk_debug_set_h16_chain / _w42_chain(0)) disable the forms; for wp_format 7 / 8 the default (1)
+ * uses the form where the 16-row kernel would run, 2 wherever the sequence is eligible.
  * srk_conv3x3_seq_kernel_name: name of the one kernel the sequence goes to, "" if it is launched conv by conv. */
 int srk_conv3x3_seq_kernel_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_debug_set_h16_chain(int mode);
 int srk_debug_set_w42_chain(int mode);
+/* pending fault code (1: census, 2: flag wait; 0: none) after waiting for the device, cleared; < 0: error.  See above. */
+int srk_chain_recover(void);
+/* chain launches so far / wrap resets of the flag epoch / recovered time-outs / sequence calls left in the back-off (any may be NULL) */
+int srk_chain_stats(unsigned long long* launches, unsigned long long* resets, int* strikes, long* off_calls);
+/* The flag epoch and the census count are 32-bit and compared as differences; before either would pass 2^30 the library zeroes them and the
+ * flag array on the launching stream.  This is that decision as pure arithmetic (CPU-testable): given the current values and the next
+ * launch (n convs, `tiles` workgroups) it returns the values the launch uses and whether the reset precedes it. */
+int srk_chain_epoch_plan(unsigned epoch, unsigned arrive_base, int n, int tiles, unsigned* epoch_out, unsigned* arrive_out, int* reset);
+/* bound of the census wait in microseconds (0: back to SRK_CHAIN_ENTRY_MS / 50 ms).  A data-parallel job sets it to seconds: a
+ * collective's kernel holds CUs while a peer rank is late, and a chain launch behind it has to wait that out. */
+int srk_chain_set_entry_us(unsigned us);
+/* test aids: set the epoch (to cross the wrap in a test) and the back-off; pretend a launch timed out; occupy `workgroups` CUs for `usec`
+ * microseconds on `stream` (one 4-wave workgroup with 64 KB of LDS each: no chain workgroup fits beside it) -- the stand-in for a
+ * collective's kernel in tools/debug/holder_bench.py */
+int srk_debug_chain_set(unsigned epoch, long off_calls);
+int srk_debug_chain_inject_fault(unsigned code);
+int srk_debug_chain_inject_fault_async(void* stream);     /* the same from the device side of `stream`, in stream order */
+int srk_debug_hold_cus(int workgroups, int usec, void* stream);
 
 /* Weight-gradient of the same convolution:
  *   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]
@@ -324,7 +357,8 @@ int srk_conv3x3_wgrad_flat(const void* x, int ldc_in, int c_in_off, int Cin, con
  * optimizers): fp32 parameters, gradients, exp_avg, exp_avg_sq behind a device table of pointers.  Arithmetic of ATen's fused Adam
  * (amsgrad off, maximize off): g /= *grad_scale (if given); g += weight_decay * p; exp_avg = lerp(exp_avg, g, 1 - beta1);
  * exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) g^2; p -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps) with
- * t = *step (device, already incremented by the caller); nothing is touched when *found_inf != 0 (torch.amp.GradScaler's contract).
+ * t = *step (device, already incremented by the caller: srk_adam_count_step); nothing is touched when *found_inf != 0 (torch.amp.GradScaler's
+ * contract; srk_adam_count_step folds a pending chain fault into that word).
  * srk_adam_plan fills chunk_begin of a host table and returns the launch size; the caller copies the table to the device. */
 typedef struct srk_adam_entry {
   float* p; const float* g; float* m; float* v;
@@ -338,6 +372,12 @@ int srk_adam_step(const srk_adam_entry* device_entries, int n, int64_t total_chu
  * every step, as a discriminator's are) */
 int srk_adam_step_small(const srk_adam_entry* host_entries, int n, int64_t total_chunks, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
+
+/* The counting half of an Adam step, and the ONE place where a step decides whether it happens: skip = (*found_inf != 0, found_inf may
+ * be NULL) or a chain launch's fault is pending (srk_conv3x3_seq above; read on the device).  *skip_out = skip ? 1 : 0 (may be NULL),
+ * *step += 1 unless skip (ATen: _foreach_add_(steps, 1) ... _foreach_sub_(steps, found_inf): a skipped update is not counted).  The
+ * caller passes skip_out as the found_inf of srk_adam_step: all of its workgroups then act on the same decision. */
+int srk_adam_count_step(float* step, const float* found_inf, float* skip_out, void* stream);
 
 const char* srk_strerror(int status);
 int srk_version(void);

@@ -15,14 +15,17 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3_signs_bytes", "srk_conv3x3_seq_signs_bytes", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_debug_set_wgrad_w22_form", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3_signs_bytes", "srk_conv3x3_seq_signs_bytes", "srk_conv3x3_seq_signs_tag", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_debug_set_wgrad_w22_form", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_lrelu_grad_mul", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_jet_extract", "srk_strerror", "srk_version",
+    "srk_chain_recover", "srk_chain_stats", "srk_chain_epoch_plan", "srk_debug_chain_set", "srk_chain_set_entry_us", "srk_debug_chain_inject_fault",
+    "srk_debug_hold_cus", "srk_adam_count_step", "srk_debug_chain_inject_fault_async",
 ]
+ERR_CHAIN_TIMEOUT = -6
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD = 0, 1, 2
 
 _fp = C.c_void_p
@@ -69,6 +72,15 @@ class AdamEntry(C.Structure):
 
 
 _lib = None
+dispatch_gen = 0
+
+
+def _bumping(fn):
+    def call(*a):
+        global dispatch_gen
+        dispatch_gen += 1
+        return fn(*a)
+    return call
 
 
 def lib():
@@ -147,13 +159,55 @@ def lib():
         L.srk_hitogram_bwd.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp]
         L.srk_soft_hist_fwd.argtypes = [_fp, C.c_long, _fp, _fp, C.c_int, C.c_float, C.c_int, _fp, _fp, C.c_size_t, _fp]
         L.srk_soft_hist_bwd.argtypes = [_fp, C.c_long, _fp, _fp, C.c_int, C.c_float, C.c_int, _fp, _fp, _fp]
+        L.srk_conv3x3_seq_signs_tag.argtypes = [C.POINTER(ConvArgs), C.c_int]
+        L.srk_chain_recover.argtypes = []
+        L.srk_chain_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        L.srk_chain_epoch_plan.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+        L.srk_debug_chain_set.argtypes = [C.c_uint, C.c_long]
+        L.srk_chain_set_entry_us.argtypes = [C.c_uint]
+        L.srk_debug_chain_inject_fault.argtypes = [C.c_uint]
+        L.srk_debug_chain_inject_fault_async.argtypes = [_fp]
+        L.srk_debug_hold_cus.argtypes = [C.c_int, C.c_int, _fp]
+        L.srk_adam_count_step.argtypes = [_fp, _fp, _fp, _fp]
+        # whatever changes which kernel form a launch takes bumps dispatch_gen: callers that cache a dispatch-dependent answer (the engine's
+        # sign-bit decisions) key it with the generation
+        for name in ("srk_debug_set_h16_mt", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_debug_set_wino42_nmt",
+                     "srk_chain_recover", "srk_debug_chain_set"):
+            setattr(L, name, _bumping(getattr(L, name)))
         _lib = L
     return _lib
 
 
+class ChainTimeout(RuntimeError):
+    """SRK_ERR_CHAIN_TIMEOUT: a chain launch (one persistent kernel per dense-block sequence) gave up -- its grid was not resident within
+    the census bound, or a flag wait timed out.  The call that raised launched nothing; optimizer steps skip themselves on the device
+    while the fault is pending.  chain_recover(), then repeat the iteration (train.Stepper.step does both)."""
+
+
 def check(status: int, what: str):
+    if status == ERR_CHAIN_TIMEOUT:
+        raise ChainTimeout(f"{what}: {lib().srk_strerror(status).decode()} (status {status})")
     if status != 0:
         raise RuntimeError(f"{what} failed: {lib().srk_strerror(status).decode()} (status {status})")
+
+
+def chain_recover() -> int:
+    """srk_chain_recover: waits for the device, clears a pending chain fault, rests the chain forms; returns the fault code (0: none)."""
+    rc = lib().srk_chain_recover()
+    if rc < 0:
+        check(rc, "srk_chain_recover")
+    return rc
+
+
+def chain_stats() -> dict:
+    a, b, c, d = C.c_ulonglong(0), C.c_ulonglong(0), C.c_int(0), C.c_long(0)
+    check(lib().srk_chain_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "srk_chain_stats")
+    return {"launches": a.value, "resets": b.value, "strikes": c.value, "off_calls": d.value}
+
+
+def adam_count_step(step, found_inf, skip_out):
+    """srk_adam_count_step: *step += 1 unless *found_inf != 0 or a chain fault is pending; *skip_out = 1 / 0 accordingly"""
+    check(lib().srk_adam_count_step(step.data_ptr(), ptr(found_inf), skip_out.data_ptr(), stream_ptr()), "srk_adam_count_step")
 
 
 def stream_ptr() -> int:
@@ -276,6 +330,17 @@ def conv_seq_signs_bytes(calls) -> int:
     for a, (x, wp, bias, y, kw) in zip(arr, calls):
         _fill_conv_args(a, x, wp, bias, y, **kw)
     return int(lib().srk_conv3x3_seq_signs_bytes(arr, n))
+
+
+def conv_seq_signs(calls):
+    """(bytes of ONE conv's sign-bit buffer, layout tag) of the sequence `calls`; (0, 0) if its launches offer no sign bits.  Bits written
+    under one tag may only be read by a sequence reporting the same tag (srk_conv3x3_seq_signs_tag)."""
+    n = len(calls)
+    arr = (ConvArgs * n)()
+    for a, (x, wp, bias, y, kw) in zip(arr, calls):
+        _fill_conv_args(a, x, wp, bias, y, **kw)
+    nb = int(lib().srk_conv3x3_seq_signs_bytes(arr, n))
+    return (nb, int(lib().srk_conv3x3_seq_signs_tag(arr, n))) if nb else (0, 0)
 
 
 def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):

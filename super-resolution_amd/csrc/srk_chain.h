@@ -6,13 +6,23 @@
 // instead of through a kernel boundary.  Rules every form keeps:
 //   * at most one workgroup per CU (host-checked against the device) and at most ONE chain kernel in flight per device (the host
 //     orders launches on different streams by an event): no workgroup waits for a tile that cannot become resident;
-//   * a tile publishes conv k before it waits for anybody's conv k (no cycle), and every wait is bounded (SRK_CHAIN_WAIT_TICKS = 30 s: an all-reduce kernel holding CUs while a peer rank
-//     is seconds late must not trip it): on a time-out the
-//     kernel sets *err and goes on, so it always drains; the host turns the word into an error on its next call and switches the
-//     chain forms off;
+//   * CENSUS (round 4): before a workgroup stores anything or waits for anybody, every workgroup of the launch has counted itself in
+//     (srk_chain_census_*: one atomic add per workgroup on a device word, then a bounded wait -- SRK_CHAIN_ENTRY_MS, 50 ms -- until
+//     the count has reached the launch's target).  If the grid is not resident by then (a foreign process on the GPU, a kernel of
+//     another stream holding CUs for longer than that) the launch gives up BEFORE any arithmetic has consumed unpublished data and
+//     before any store: the first workgroup to time out poisons the count word by compare-and-swap -- which can only succeed while
+//     the count is short of the target, so all workgroups reach the same verdict --, sets *err = 1 and every workgroup returns;
+//   * a tile publishes conv k before it waits for anybody's conv k (no cycle), and every flag wait is bounded as well
+//     (SRK_CHAIN_WAIT_TICKS = 30 s; with the census in front it can only trip on a fault): it sets *err = 2 and goes on, so the
+//     kernel always drains;
+//   * *err != 0 makes srk_adam_step skip its update ON THE DEVICE (the word is host memory the device reads: no round trip), and the
+//     next srk_conv3x3_seq / srk_adam_step call on the host returns SRK_ERR_CHAIN_TIMEOUT until srk_chain_recover() has been called:
+//     weights and optimizer state never see gradients of a launch that timed out (train.Stepper re-runs the iteration);
 //   * a conv reads from its predecessor's output only through its LAST 64 input channels, fetched behind the wait; nobody reads a
 //     slice before it is written, slices are whole 128-byte lines, and an L2 holds nothing from before the launch, so no XCD can
-//     hold a stale copy of what it fetches behind the wait.
+//     hold a stale copy of what it fetches behind the wait;
+//   * epoch and census count are 32-bit and compared as differences; the host zeroes flags and count (on the launching stream) before
+//     either passes 2^30 (srk_chain_epoch_plan), so no stale flag can ever compare as "ready" after a wrap.
 #pragma once
 #include "srk_internal.h"
 
@@ -20,15 +30,46 @@ constexpr int SRK_CHAIN_MAX = 8;          // convolutions per launch
 constexpr int SRK_CHAIN_FLAGS = 1024;     // tiles per launch (>= CUs of the device)
 constexpr unsigned long long SRK_CHAIN_WAIT_TICKS = 3000000000ull;     // 30 s of the 100 MHz s_memrealtime counter
 
+constexpr unsigned SRK_CHAIN_POISON = 0x80000000u;     // bit of the census word: a launch has given up (stays until srk_chain_recover)
+constexpr unsigned SRK_CHAIN_WRAP = 1u << 30;           // epoch / census count are zeroed by the host before they pass this
+
 struct srk_chain_args {
   srk_conv_args c[SRK_CHAIN_MAX];
   int n;
   unsigned epoch;
   unsigned* flags;
   unsigned* err;
+  unsigned* arrive;            // census word (device, uncached): workgroups of all chain launches so far | SRK_CHAIN_POISON
+  unsigned arrive_target;      // its value once every workgroup of THIS launch has counted itself in
+  unsigned entry_ticks;        // bound of the census wait (100 MHz ticks)
 };
 
 #if defined(__HIPCC__)
+// ---- census: is every workgroup of this launch resident?  Called by ONE lane of the workgroup.
+// step 1, at kernel entry: count me in.  Returns false if an earlier launch has poisoned the word (the host has not recovered yet).
+__device__ __forceinline__ bool srk_chain_census_arrive(const srk_chain_args& A) {
+  const unsigned old = __hip_atomic_fetch_add(A.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (old & SRK_CHAIN_POISON) == 0;
+}
+// step 2, before the workgroup's first store / first flag wait: true = all resident, go; false = give up (nothing touched so far).
+// The verdict is the same for every workgroup: the poison bit can only be set while the count is short of the target.
+__device__ __forceinline__ bool srk_chain_census_wait(const srk_chain_args& A) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned w = __hip_atomic_load(A.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w & SRK_CHAIN_POISON) return false;
+    if (w == A.arrive_target) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)A.entry_ticks) {
+      unsigned expect = w;
+      if (__hip_atomic_compare_exchange_strong(A.arrive, &expect, w | SRK_CHAIN_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+      continue;            // (somebody arrived or poisoned in between: look again)
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 // The neighbour lane `lane` (0..8: dy = lane / 3 - 1, dx = lane % 3 - 1) of tile (n, ty, tx) watches; lanes that watch nothing read the
 // tile's own flag and ignore it.
 struct srk_chain_watch {
@@ -49,7 +90,7 @@ __device__ __forceinline__ void srk_chain_wait(const srk_chain_watch& w, unsigne
     const unsigned v = w.on ? __hip_atomic_load(w.fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
     if (__all((int)(v - target) >= 0)) break;
     if (__builtin_amdgcn_s_memrealtime() - t0 > SRK_CHAIN_WAIT_TICKS) {
-      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
     __builtin_amdgcn_s_sleep(4);
@@ -82,12 +123,21 @@ __device__ __forceinline__ bool srk_chain_wait_scalar(const unsigned* flags, int
 // ---- host side (srk_chain.hip)
 int srk_chain_cus();                       // CUs of the current device, 0 if the chain forms cannot be used on it
 bool srk_chain_flags_uncached();           // the flag array is uncached memory (srk_chain_wait_scalar may be used)
-// Claims the device for one chain launch on `st`: 1 = go (A->epoch / flags / err filled for n convs, `st` ordered behind the previous chain
-// launch; call srk_chain_end afterwards), 0 = not now (stream capture, forms switched off), < 0 = error (a time-out of an earlier launch)
-int srk_chain_begin(hipStream_t st, int n, srk_chain_args* A);
+// Claims the device for one chain launch of `tiles` workgroups on `st`: 1 = go (A->epoch / flags / err / census fields filled for n convs,
+// `st` ordered behind the previous chain launch; call srk_chain_end afterwards), 0 = not now (stream capture, forms switched off or backing
+// off after a time-out), < 0 = error (SRK_ERR_CHAIN_TIMEOUT: an earlier launch timed out and srk_chain_recover has not been called)
+int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A);
 int srk_chain_end(hipStream_t st, bool launched);
+// true while the chain forms rest after a recovered time-out (sequences go conv by conv); tick: this is a launch attempt, count it off
+bool srk_chain_resting(bool tick);
+// != 0 while a time-out is pending (1: census, 2: flag wait); a relaxed read of host memory
+unsigned srk_chain_fault();
+// the word itself (host memory, device-readable) for kernels that must not act on a faulted launch's results (srk_adam_step); nullptr if
+// no chain kernel has run on this device
+const unsigned* srk_chain_fault_word();
 // do channels [ca, ca + na) of view (pa, lda) and [cb, cb + nb) of (pb, ldb) share memory?  (px pixels per tensor, esz bytes per element)
 bool srk_chain_views_overlap(const void* pa, int lda, int ca, int na, const void* pb, int ldb, int cb, int nb, long px, int esz);
 // the dense-block pattern over args[0..n): one geometry, <= 64 outputs, whole 64-channel slices on 128-byte lines, every conv >= 1 with
-// >= 128 inputs of which only the last 64 may come from its predecessor's output, no conv writing what it reads
+// >= 128 inputs of which only the last 64 may come from its predecessor's output, no conv writing what it or a LATER conv reads with
+// plain loads, no auxiliary view (r1 / r2 / mask / signs) overlapping an output of the sequence
 bool srk_chain_pattern_ok(const srk_conv_args* args, int n, int esz);

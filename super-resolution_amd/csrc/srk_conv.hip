@@ -1088,7 +1088,9 @@ int srk_conv_wino42_nmt(const srk_conv_args& a);
 int srk_launch_conv_h16(const srk_conv_args& a, hipStream_t st);         // srk_conv_h16.hip (wp_format 7 / 8)
 int srk_conv_h16_name(const srk_conv_args& a, char* buf, size_t len);
 size_t srk_conv_h16_signs_bytes(const srk_conv_args& a);
+int srk_conv_h16_mt(const srk_conv_args& a);
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st);   // 1: launched as one chain kernel, 0: not eligible, < 0: error
+unsigned srk_chain_fault();          // (srk_chain.h) != 0 while a chain launch's time-out is pending
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n);
 int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st);   // the same for the fp32 F(2x4,3x3) kernel (wp_format 6)
@@ -1178,6 +1180,9 @@ extern "C" int srk_conv3x3(const srk_conv_args* pa, void* stream) {
 
 extern "C" int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream) {
   if (!args || n <= 0) return SRK_ERR_BAD_ARG;
+  // a chain launch that gave up (srk_chain.h): nothing more goes out until the caller has recovered, so that the iteration is repeated
+  // rather than continued on activations that were never computed
+  if (srk_chain_fault()) return SRK_ERR_CHAIN_TIMEOUT;
   if (n >= 2) {
     // a dense block's sequence as ONE persistent launch (the chain forms: srk_chain.h; 16-bit storage and the fp32 F(2x4,3x3) kernel)
     const int fmt = args[0].wp_format;
@@ -1206,9 +1211,28 @@ extern "C" size_t srk_conv3x3_seq_signs_bytes(const srk_conv_args* args, int n) 
   if (fmt == 7 || fmt == 8) {
     size_t b = srk_conv_h16_signs_bytes(args[0]);
     for (int i = 1; i < n && b; ++i) if (srk_conv_h16_signs_bytes(args[i]) != b) b = 0;
+    // (a chain kernel indexes the buffer by its 16-row tiles; where the one-conv launches of this geometry would run 8-row tiles the buffer
+    // they ask for is larger, never smaller: 2 x the tiles x the same bytes per tile)
     return b;
   }
   if (fmt == 6 && n >= 2) return srk_conv_w42_chain_signs_bytes(args, n);
+  return 0;
+}
+
+// Layout tag of those sign bits: rows of the workgroup tile that writes / reads them (8 or 16) | wp_format << 8; 0 = no sign bits.  A
+// forward sequence and the data-gradient sequence that reads its bits may be dispatched differently (a chain kernel works on 16-row tiles
+// wherever it runs, the one-conv kernels on 8 or 16 by launch size; debug switches; the chain forms resting after a time-out): the caller
+// uses the bits only when both sequences report the SAME tag, else it passes the mask tensors.
+extern "C" int srk_conv3x3_seq_signs_tag(const srk_conv_args* args, int n) {
+  if (!args || n <= 0 || srk_conv3x3_seq_signs_bytes(args, n) == 0) return 0;
+  const int fmt = args[0].wp_format;
+  if (fmt == 7 || fmt == 8) {
+    int rows;
+    if (n >= 2 && srk_conv_h16_chain_would(args, n) == 1) rows = 16;
+    else { const int mt = srk_conv_h16_mt(args[0]); rows = mt == 1 ? 8 : 4 * mt; }
+    return rows | (fmt << 8);
+  }
+  if (fmt == 6) return (16 * srk_conv_wino42_nmt(args[0])) | (fmt << 8);
   return 0;
 }
 

@@ -744,6 +744,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
   typedef HGeo<MT> G;
   __shared__ float4 smem[2 * G::STAGE4 + 1];
   unsigned* const wg_cnt = reinterpret_cast<unsigned*>(smem + 2 * G::STAGE4);
+  volatile unsigned* const wg_go = wg_cnt + 1;           // the census verdict (srk_chain.h): 1 = every workgroup is resident, 2 = give up
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -768,6 +769,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     const int lw = wv - 4;
     constexpr int NXJ = (G::HPIECES + CH_NLOAD - 1) / CH_NLOAD, NWJ = G::WPIECES / CH_NLOAD;
     const unsigned wvo = (unsigned)(lane * 16);
+    // census, step 1: loader wave 0 counts the workgroup in before anything else (its verdict is due before conv 0's epilogue)
+    bool census_in = true;
+    if (lw == 0 && lane == 0) census_in = srk_chain_census_arrive(A);
     const srk_chain_watch watch = srk_chain_watch_of(A.flags, lane, n, ty, tx, tilesH, tilesW);     // lanes 0..8: the eight neighbouring tiles
     auto wait_flags = [&](unsigned target) { srk_chain_wait(watch, target, A.err, lane); };
     unsigned xvo[NXJ];
@@ -823,6 +827,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
           const bool fresh = H16_CHAIN_FRESH_DEV && c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
           if (c > 0 && q + 1 == nq - 2) { H16C_STAMP(256, c, 4); wait_flags(A.epoch + (unsigned)c); H16C_STAMP(256, c, 5); }
           stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && c > 0));
+          if (c == 0 && q == 0 && lw == 0) {
+            // census, step 2, beside the first stage's MFMAs and with stage 1 in flight: wait (bounded) until the whole grid is resident.
+            // The verdict goes through the LDS; every wave reads it behind the last stage barrier of conv 0 (>= one barrier from here),
+            // i.e. before the first store and before the first flag wait of the launch.
+            if (lane == 0) { *wg_go = (census_in && srk_chain_census_wait(A)) ? 1u : 2u; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
           if (c > 0 && q == 0 && lw == 0) {
             // publish conv c - 1 of this tile: once the four MFMA waves have seen their stores acknowledged (they count themselves in
             // a third of the way into this stage), write the XCD's dirty lines back and release the flag -- from here, so that the
@@ -838,6 +849,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
+      if (c == 0 && *wg_go != 1u) return;              // census failed: all six waves leave here (the MFMA waves in front of their epilogue)
     }
     return;
   }
@@ -957,6 +969,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     H16C_STAMP(0, c, 1);
+    if (c == 0 && *wg_go != 1u) return;                // census (srk_chain.h): the grid is not resident -- nothing has been stored
     const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
     if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
     else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
@@ -1137,18 +1150,19 @@ extern "C" int srk_debug_set_h16_chain(int mode) { g_h16_chain = (mode >= 0 && m
 
 // 1: the sequence goes out as ONE chain launch; 0: not eligible (the caller launches the convs one by one)
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n) {
-  return h16_chain_eligible(args, n, h16_chain_mode()) ? 1 : 0;
+  return (h16_chain_eligible(args, n, h16_chain_mode()) && !srk_chain_resting(false)) ? 1 : 0;
 }
 
 // 1: launched as one chain kernel, 0: not eligible (nothing launched), < 0: error
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) {
   if (!h16_chain_eligible(args, n, h16_chain_mode())) return 0;
+  if (srk_chain_resting(true)) return 0;
   srk_chain_args A;
-  const int rc = srk_chain_begin(st, n, &A);
-  if (rc != 1) return rc;
-  for (int c = 0; c < n; ++c) A.c[c] = args[c];
   const srk_conv_args& f = args[0];
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
+  const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
+  if (rc != 1) return rc;
+  for (int c = 0; c < n; ++c) A.c[c] = args[c];
   if (f.wp_format == 7) hipLaunchKernelGGL(conv3x3_h16_chain_kernel<_Float16>, grid, dim3(CH_THREADS), 0, st, A);
   else hipLaunchKernelGGL(conv3x3_h16_chain_kernel<__bf16>, grid, dim3(CH_THREADS), 0, st, A);
   const bool ok = hipGetLastError() == hipSuccess;

@@ -74,8 +74,9 @@ __device__ unsigned long long* g_w42_stamps = nullptr;
 // neighbouring tiles' flags of conv c - 1.
 // PF (chain form of the 16-row kernel, which has registers to spare -- 428 of 512): a link fetches its successor's first halo chunk and
 // first weights in front of its own epilogue (carryP0 = the kernel's copy of those weights); the 32-row kernel cannot afford it.
+// Returns false only as link 0 of a chain whose census failed (srk_chain.h: the grid is not resident; nothing has been stored).
 template <int MODE, int NMT, bool CHAIN = false>
-__device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0, f32x2 (*carryP0)[6][2] = nullptr) {
+__device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0, f32x2 (*carryP0)[6][2] = nullptr) {
   constexpr bool PF = CHAIN && NMT == 1 && W42_CH_PREFETCH1 != 0;
   constexpr int TH = 16 * NMT, IH = TH + 2, IW = SRK_TW + 2;
   constexpr int HS4 = NMT == 2 ? 640 : 384;         // slots per k-half: 37 per row pair (17 resp. 9 pairs), padded to whole instructions
@@ -95,6 +96,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   // the K loop, where there is not one register to spare: the allocator then spills accumulator tiles inside the loop)
   if constexpr (CHAIN) asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63;
+  // CHAIN, link 0: the census (srk_chain.h).  Thread 0 counts the workgroup in before anything else; its verdict is needed in front of the
+  // K loop (below), by which time -- the halo address arithmetic and the first chunk's flight lie in between -- every workgroup of a
+  // resident grid has long arrived, so the wait costs one load that returns beside the first chunk.
+  __shared__ unsigned census_go;
+  bool census_in = true;
+  if constexpr (CHAIN) { if (c == 0 && tid == 0) census_in = srk_chain_census_arrive(*A); }
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // = row position p of this wave
   const int hl = lane >> 5, l32 = lane & 31;
   const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
@@ -380,6 +387,9 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
   }
   W42_STAMP(1);
+  if constexpr (CHAIN) {
+    if (c == 0 && tid == 0) census_go = (census_in && srk_chain_census_wait(*A)) ? 1u : 2u;      // (visible behind the barrier below)
+  }
   __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
 #pragma unroll
   for (int t = 0; t < 12 * NMT; ++t)
@@ -396,6 +406,10 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if constexpr (CHAIN) {
+    // the grid is not resident (census): leave before anything is stored or waited for; every workgroup of the launch takes this exit
+    if (c == 0 && *reinterpret_cast<volatile unsigned*>(&census_go) != 1u) return false;
   }
   W42_STAMP(2);
   if constexpr (LDSW) {
@@ -514,11 +528,12 @@ __device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_ch
     //  the next conv's first halo chunk issued in front of this epilogue 480 / 496, + its first weights 508 / 522, both behind the
     //  epilogue 481 / 495, the flag raised inside the next conv's K loop instead of here 465 / 480 -- whatever stays live across the
     //  conv boundary costs this kernel more in spills than the overlap returns.)
-    if (!waited_ok && lane == 0) __hip_atomic_store(A->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!waited_ok && lane == 0) __hip_atomic_store(A->err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (tid == 0 && c + 1 < A->n) __hip_atomic_store(A->flags + tile, A->epoch + (unsigned)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  return true;
 }
 
 template <int MODE, int NMT>
@@ -531,7 +546,9 @@ __global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_
 template <int NMT>
 __global__ __launch_bounds__(256) void conv3x3_f32_wino42_chain_kernel(const srk_chain_args A) {
   f32x2 P0[6][2];          // (16-row form: the next conv's first weights, fetched by the previous link)
-  for (int c = 0; c < A.n; ++c) wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0);
+  for (int c = 0; c < A.n; ++c) {
+    if (!wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0)) return;
+  }
 }
 
 }  // namespace
@@ -596,7 +613,7 @@ static bool w42_chain_eligible(const srk_conv_args* args, int n) {
   return srk_chain_pattern_ok(args, n, 4);
 }
 
-int srk_conv_w42_chain_would(const srk_conv_args* args, int n) { return w42_chain_eligible(args, n) ? 1 : 0; }
+int srk_conv_w42_chain_would(const srk_conv_args* args, int n) { return (w42_chain_eligible(args, n) && !srk_chain_resting(false)) ? 1 : 0; }
 
 // bytes of one conv's sign-bit buffer when the sequence goes out as a chain kernel (which has sign bits); 0 otherwise
 size_t srk_conv_w42_chain_signs_bytes(const srk_conv_args* args, int n) {
@@ -615,13 +632,14 @@ int srk_conv_w42_chain_name(const srk_conv_args* args, int n, char* buf, size_t 
 // 1: launched as one chain kernel, 0: not eligible (nothing launched), < 0: error
 int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st) {
   if (!w42_chain_eligible(args, n)) return 0;
+  if (srk_chain_resting(true)) return 0;
   srk_chain_args A;
-  const int rc = srk_chain_begin(st, n, &A);
-  if (rc != 1) return rc;
-  for (int c = 0; c < n; ++c) A.c[c] = args[c];
   const srk_conv_args& f = args[0];
   const int nmt = srk_conv_wino42_nmt(f);
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16 * nmt) * srk_div_up(f.W, SRK_TW)));
+  const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
+  if (rc != 1) return rc;
+  for (int c = 0; c < n; ++c) A.c[c] = args[c];
   if (nmt == 2) hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<2>, grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<1>, grid, dim3(256), 0, st, A);
   const bool ok = hipGetLastError() == hipSuccess;

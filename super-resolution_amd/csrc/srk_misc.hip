@@ -495,6 +495,7 @@ extern "C" const char* srk_strerror(int s) {
     case SRK_ERR_ALIGNMENT: return "view is not 16-byte aligned for the vector path";
     case SRK_ERR_WORKSPACE: return "workspace missing or too small";
     case SRK_ERR_LAUNCH: return "kernel launch failed";
+    case SRK_ERR_CHAIN_TIMEOUT: return "a conv3x3 chain launch gave up (grid not resident within its bound, or a flag wait timed out): call srk_chain_recover() and repeat the iteration";
     default: return "unknown srk status";
   }
 }

@@ -6,7 +6,11 @@
 // Arithmetic as ATen's fused Adam (fused_adam_utils.cuh), in fp32 with the bias corrections formed in double from a device step
 // counter: grad /= grad_scale (optional), L2 weight decay into the gradient, exp_avg by lerp, exp_avg_sq, param -= lr / bc1 *
 // exp_avg / (sqrt(exp_avg_sq) / sqrt(bc2) + eps); skipped altogether when *found_inf != 0 (torch.amp.GradScaler).
+// srk_adam_count_step is the counting half of a step and the place where ONE decision per step is taken: it folds the fault word of the
+// chain kernels (srk_chain.h: a launch that gave up leaves garbage in the gradient buffers; the word is host memory the device reads, so
+// no round trip however far the host has run ahead) into the skip word the update kernel then reads as its found_inf.
 #include "srk_internal.h"
+#include "srk_chain.h"
 #include <math.h>
 
 namespace {
@@ -75,7 +79,20 @@ __global__ __launch_bounds__(256) void adam_small_kernel(const adam_small_table 
                                                           const float* __restrict__ found_inf) {
   adam_body(T.e, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf);
 }
+__global__ void adam_count_kernel(float* step, const float* found_inf, float* skip_out, const unsigned* fault) {
+  const bool skip = (found_inf && *found_inf != 0.f) || (fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
+  if (skip_out) *skip_out = skip ? 1.f : 0.f;
+  if (!skip) *step += 1.f;
+}
 }  // namespace
+
+extern "C" int srk_adam_count_step(float* step, const float* found_inf, float* skip_out, void* stream) {
+  if (!step) return SRK_ERR_BAD_ARG;
+  if (srk_chain_fault()) return SRK_ERR_CHAIN_TIMEOUT;
+  hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, found_inf, skip_out, srk_chain_fault_word());
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
 
 extern "C" int srk_adam_plan(srk_adam_entry* host_entries, int n, int64_t* total_chunks) {
   if (!host_entries || n <= 0 || !total_chunks) return SRK_ERR_BAD_ARG;
@@ -95,6 +112,7 @@ extern "C" int srk_adam_step_small(const srk_adam_entry* host_entries, int n, in
   if (!host_entries || n <= 0 || n > ADAM_SMALL || total_chunks <= 0 || total_chunks > 0x7fffffffL || !step) return SRK_ERR_BAD_ARG;
   if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return SRK_ERR_BAD_ARG;
   if (1.f - beta1 >= 0.5f) return SRK_ERR_UNSUPPORTED;
+  if (srk_chain_fault()) return SRK_ERR_CHAIN_TIMEOUT;
   adam_small_table T;
   for (int i = 0; i < n; ++i) T.e[i] = host_entries[i];
   for (int i = n; i < ADAM_SMALL; ++i) T.e[i] = host_entries[n - 1];
@@ -109,6 +127,7 @@ extern "C" int srk_adam_step(const srk_adam_entry* device_entries, int n, int64_
   if (!device_entries || n <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffL || !step) return SRK_ERR_BAD_ARG;
   if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return SRK_ERR_BAD_ARG;
   if (1.f - beta1 >= 0.5f) return SRK_ERR_UNSUPPORTED;          // (lerp's other branch: beta1 <= 0.5 is not Adam as anybody runs it)
+  if (srk_chain_fault()) return SRK_ERR_CHAIN_TIMEOUT;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, device_entries, n, lr, beta1, beta2, eps,
                      weight_decay, step, grad_scale, found_inf);
   SRK_CHECK_LAUNCH();

@@ -85,7 +85,11 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
+  // The bias gradient is a plain sum of dy over every pixel -- for the discriminators a difference of nearly equal sums (real minus fake
+  // pass, esrgan.py:578-581: at 32 x 256 x 256 float32 arithmetic of ANY order is 2e-3 ... 1e-2 of the tensor's max away from the float64
+  // result).  It costs two instructions per nine MFMAs to keep it in double all the way: here, through the LDS, and in the partials
+  // ((hi, lo) float pairs, WBatch::bias_lo), so that this path adds nothing to what float32 dy values already carry.
+  double bsum = 0.0;
 
   const int t_begin = p * B.tpb;
   int t_end = t_begin + B.tpb;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
         const int cur = kk & 1;
         if (kk + 1 < KQ) ld_k(cur ^ 1, kk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (do_bias) bsum += av[cur];
+        if (do_bias) bsum += (double)av[cur];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][tap], acc[tap], 0, 0, 0);
@@ -256,11 +260,16 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       }
       __syncthreads();
     }
-    if (ks > 0) smem[9216 + ((ks - 1) * NL + tl) * 64 + lane] = bsum;
+    if (ks > 0) {
+      const float hi = (float)bsum;
+      smem[9216 + ((ks - 1) * NL + tl) * 64 + lane] = hi;
+      smem[9216 + 256 + ((ks - 1) * NL + tl) * 64 + lane] = (float)(bsum - (double)hi);
+    }
     __syncthreads();
     if (ks == 0)
 #pragma unroll
-      for (int q = 1; q < KSP; ++q) bsum += smem[9216 + ((q - 1) * NL + tl) * 64 + lane];
+      for (int q = 1; q < KSP; ++q)
+        bsum += (double)smem[9216 + ((q - 1) * NL + tl) * 64 + lane] + (double)smem[9216 + 256 + ((q - 1) * NL + tl) * 64 + lane];
   }
   // ---- write partial block: part[p][chunk][tap][64 cout][64 cin]
   if (active && ks == 0) {
@@ -274,8 +283,13 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       }
   }
   if (do_bias && ks == 0) {
-    const float tot = bsum + __shfl_xor(bsum, 32);
-    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
+    const double tot = bsum + __shfl_xor(bsum, 32);
+    const float hi = (float)tot;
+    if (hl == 0) {
+      const size_t at = ((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32;
+      pbias[at] = hi;
+      if (B.bias_lo) (part + B.lo_off)[at] = (float)(tot - (double)hi);
+    }
   }
 }
 
@@ -770,7 +784,8 @@ __global__ __launch_bounds__(BW_THREADS) void wgrad_bf16x3_kernel(const WBatch B
 
 // grid (64 local cout rows, n_chunks), 576 threads = (tap, 64 cin).  Sums the P partials in fixed order,
 // transposes [tap][c] -> [c][tap] through LDS and writes one contiguous OIHW row segment dW[o][c0..c0+63][0..8].
-__global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias) {
+__global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias,
+                                                           const float* __restrict__ plo) {
   __shared__ float row[576];
   const int chunk = blockIdx.y, ol = blockIdx.x, t = threadIdx.x;
   const WProb& a = B.prob[B.c_prob[chunk]];
@@ -780,18 +795,20 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
   const int tap = t >> 6, cl = t & 63;
   const size_t stride = (size_t)B.n_chunks * CHUNK_FLOATS;
   const float* src = part + (size_t)chunk * CHUNK_FLOATS + (tap * 64 + ol) * 64 + cl;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // (the partials are summed in double: the loads pace this kernel, and a discriminator layer's 512 pixel splits -- gradients that are
+  // differences of nearly equal sums, see wgrad_f32_kernel -- then add no rounding of their own)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (cy * 64 + cl < a.Cin) {     // partial blocks of padding waves are never written
     int p = 0;
     for (; p + 4 <= B.P; p += 4) {
-      s0 += src[(size_t)p * stride];
-      s1 += src[(size_t)(p + 1) * stride];
-      s2 += src[(size_t)(p + 2) * stride];
-      s3 += src[(size_t)(p + 3) * stride];
+      s0 += (double)src[(size_t)p * stride];
+      s1 += (double)src[(size_t)(p + 1) * stride];
+      s2 += (double)src[(size_t)(p + 2) * stride];
+      s3 += (double)src[(size_t)(p + 3) * stride];
     }
-    for (; p < B.P; ++p) s0 += src[(size_t)p * stride];
+    for (; p < B.P; ++p) s0 += (double)src[(size_t)p * stride];
   }
-  row[cl * 9 + tap] = a.scale * ((s0 + s1) + (s2 + s3));
+  row[cl * 9 + tap] = (float)((double)a.scale * ((s0 + s1) + (s2 + s3)));
   __syncthreads();
   int os = o;
   if (B.dy_mode == SRK_IN_UNSHUFFLE) { const int Cps = a.Cout >> 2; os = 4 * (o % Cps) + o / Cps; }
@@ -801,9 +818,16 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
     *d = a.accumulate ? (*d + row[t]) : row[t];
   }
   if (a.db && cy == 0 && t == 0) {
-    float s = 0.f;
-    for (int q = 0; q < B.P; ++q) s += pbias[((size_t)q * B.n_chunks + chunk) * 64 + ol];
-    a.db[os] = a.accumulate ? (a.db[os] + a.scale * s) : a.scale * s;
+    // (in double: 64 sums per layer, free; with bias_lo the partials are (hi, lo) pairs of double sums)
+    double s = 0.0;
+    const float* lo = plo;
+    for (int q = 0; q < B.P; ++q) {
+      const size_t at = ((size_t)q * B.n_chunks + chunk) * 64 + ol;
+      s += (double)pbias[at];
+      if (lo) s += (double)lo[at];
+    }
+    const float v = (float)((double)a.scale * s);
+    a.db[os] = a.accumulate ? (a.db[os] + v) : v;
   }
 }
 
@@ -812,7 +836,8 @@ __global__ __launch_bounds__(576) void wgrad_reduce_kernel(const WBatch B, const
 // latency (73 us at P = 512).  Here grid.z = Z slices of P are summed concurrently into Z partial blocks of the SAME
 // layout, which the kernel above then finishes with P := Z.  Fixed order in both stages (deterministic).
 __global__ __launch_bounds__(576) void wgrad_prereduce_kernel(const WBatch B, const float* __restrict__ part, const float* __restrict__ pbias,
-                                                              float* __restrict__ part2, float* __restrict__ pbias2, int per) {
+                                                              const float* __restrict__ plo, float* __restrict__ part2, float* __restrict__ pbias2,
+                                                              float* __restrict__ plo2, int per) {
   const int chunk = blockIdx.y, ol = blockIdx.x, z = blockIdx.z, t = threadIdx.x;
   const WProb& a = B.prob[B.c_prob[chunk]];
   const int cy = B.c_cy[chunk], cz = B.c_cz[chunk];
@@ -823,23 +848,33 @@ __global__ __launch_bounds__(576) void wgrad_prereduce_kernel(const WBatch B, co
   const size_t off = (size_t)chunk * CHUNK_FLOATS + (tap * 64 + ol) * 64 + cl;
   if (cy * 64 + cl < a.Cin) {
     const float* src = part + off;
-    float s[8];
+    double s[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int j = 0; j < 8; ++j) s[j] = 0.0;
     int p = p0;
     for (; p + 8 <= p1; p += 8) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += src[(size_t)(p + j) * stride];
+      for (int j = 0; j < 8; ++j) s[j] += (double)src[(size_t)(p + j) * stride];
     }
-    for (; p < p1; ++p) s[0] += src[(size_t)p * stride];
-    part2[(size_t)z * stride + off] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (; p < p1; ++p) s[0] += (double)src[(size_t)p * stride];
+    part2[(size_t)z * stride + off] = (float)(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
   }
   if (a.db && cy == 0 && t < 64) {
-    float v = 0.f;
-    for (int q = p0 + t; q < p1; q += 64) v += pbias[((size_t)q * B.n_chunks + chunk) * 64 + ol];
+    double v = 0.0;
+    const float* lo = plo;
+    for (int q = p0 + t; q < p1; q += 64) {
+      const size_t at = ((size_t)q * B.n_chunks + chunk) * 64 + ol;
+      v += (double)pbias[at];
+      if (lo) v += (double)lo[at];
+    }
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
-    if (t == 0) pbias2[((size_t)z * B.n_chunks + chunk) * 64 + ol] = v;
+    if (t == 0) {
+      const size_t at2 = ((size_t)z * B.n_chunks + chunk) * 64 + ol;
+      const float hi = (float)v;
+      pbias2[at2] = hi;
+      if (plo2) plo2[at2] = (float)(v - (double)hi);
+    }
   }
 }
 
@@ -981,6 +1016,7 @@ int build_batch(const srk_wgrad_args* args, int n, WBatch& B) {
   if (B.wino && wino22_env) { B.wino = 2; TH = W22_TH; }
   const bool h16 = a0.precision == 3 || a0.precision == 4;        // 16-bit storage (srk_wgrad_h16.hip): 8-row tiles
   B.h16 = h16 ? 1 : 0;
+  B.bias_lo = 0; B.lo_off = 0;
   if (h16) TH = W16_TH;
   B.tilesW = srk_div_up(a0.OW, WTW);
   B.tilesH = srk_div_up(a0.OH, TH);
@@ -1023,27 +1059,33 @@ int reduce_slices(const WBatch& B) {
   return z > 16 ? 16 : z;
 }
 
+// workspace: part [P][chunks][CHUNK] | pbias [P][chunks][64] | part2 [Z][chunks][CHUNK] | pbias2 [Z][chunks][64] | lo [P][chunks][64] |
+// lo2 [Z][chunks][64]  (Z = first-stage slices of the reduction; lo / lo2 = low words of the double bias sums, WBatch::bias_lo)
 size_t ws_bytes(const WBatch& B) {
   if (use_c1(B)) return (size_t)C1_BLOCKS * srk_div_up(B.prob[0].Cout, C1_CG) * C1_VALS * sizeof(float);
-  return ((size_t)(B.P + reduce_slices(B)) * B.n_chunks * (CHUNK_FLOATS + 64)) * sizeof(float);
+  return ((size_t)(B.P + reduce_slices(B)) * B.n_chunks * (CHUNK_FLOATS + 128)) * sizeof(float);
 }
+size_t ws_lo_off(const WBatch& B) { return (size_t)(B.P + reduce_slices(B)) * B.n_chunks * (CHUNK_FLOATS + 64); }
 
 // sums the P partial blocks (and bias partials) into dW / db
 int launch_reduce(const WBatch& B, float* part, float* pbias, hipStream_t st) {
   const int Z = reduce_slices(B);
+  float* plo = B.bias_lo ? part + B.lo_off : nullptr;
   if (Z == 0) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B, part, pbias, (const float*)plo);
     SRK_CHECK_LAUNCH();
     return SRK_OK;
   }
   float* part2 = pbias + (size_t)B.P * B.n_chunks * 64;
   float* pbias2 = part2 + (size_t)Z * B.n_chunks * CHUNK_FLOATS;
+  float* plo2 = plo ? plo + (size_t)B.P * B.n_chunks * 64 : nullptr;
   const int per = srk_div_up(B.P, Z);
-  hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3(64, B.n_chunks, Z), dim3(576), 0, st, B, (const float*)part, (const float*)pbias, part2, pbias2, per);
+  hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3(64, B.n_chunks, Z), dim3(576), 0, st, B, (const float*)part, (const float*)pbias, (const float*)plo,
+                     part2, pbias2, plo2, per);
   SRK_CHECK_LAUNCH();
   WBatch B2 = B;
   B2.P = srk_div_up(B.P, per);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B2, (const float*)part2, (const float*)pbias2);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, B.n_chunks), dim3(576), 0, st, B2, (const float*)part2, (const float*)pbias2, (const float*)plo2);
   SRK_CHECK_LAUNCH();
   return SRK_OK;
 }
@@ -1075,16 +1117,22 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     if (rc) return rc;
     return launch_reduce(B, part, pbias, st);
   }
-  if (S == 1 && VEC && B.wino)
+  if (S == 1 && VEC && B.wino) {
     hipLaunchKernelGGL((wgrad_f32_wino_kernel<DYMODE>), dim3(B.P * B.n_chunks), dim3(WW_THREADS), 0, st, B, part, pbias);
-  else if (DYMODE == SRK_IN_PLAIN && ksp == 4)
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+    SRK_CHECK_LAUNCH();
+    return launch_reduce(B, part, pbias, st);
+  }
+  WBatch Bd = B;              // the direct kernel keeps its bias sums in double: (hi, lo) partials
+  Bd.bias_lo = 1;
+  Bd.lo_off = ws_lo_off(B);
+  if (DYMODE == SRK_IN_PLAIN && ksp == 4)
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 2)
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
   else
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC, 1>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC, 1>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
   SRK_CHECK_LAUNCH();
-  return launch_reduce(B, part, pbias, st);
+  return launch_reduce(Bd, part, pbias, st);
 }
 
 }  // namespace
@@ -1176,7 +1224,10 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
   bool vec = true;
   for (int i = 0; i < n; ++i) vec = vec && is_vec(args[i]);
   if (a0.precision == 1 || a0.precision == 2) { snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d>", a0.dy_mode, a0.precision == 1 ? 3 : 1); return SRK_OK; }
-  if (a0.precision == 3 || a0.precision == 4) { snprintf(buf, len, "wgrad_h16_kernel<%s, %d>", a0.precision == 3 ? "_Float16" : "__bf16", a0.dy_mode); return SRK_OK; }
+  if (a0.precision == 3 || a0.precision == 4) {     // (all four template arguments: the loader form, B.h16 == 2, is what the c4 trunk runs)
+    snprintf(buf, len, "wgrad_h16_kernel<%s, %d, %s, 8>", a0.precision == 3 ? "_Float16" : "__bf16", a0.dy_mode, B.h16 == 2 ? "true" : "false");
+    return SRK_OK;
+  }
   if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d, %s>", a0.dy_mode, srk_wgrad_wino22_rows() ? "true" : "false"); return SRK_OK; }
   if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
   int ksp = 1;

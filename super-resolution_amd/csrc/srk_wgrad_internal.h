@@ -26,6 +26,8 @@ struct WBatch {
   int N, H, W, OH, OW;
   int P, tpb, tilesH, tilesW, total_tiles, n_chunks, n_prob, dy_mode, wino;
   int h16;                  // x / dy are 16-bit tensors (srk_wgrad_args.precision 3 / 4): srk_wgrad_h16.hip only
+  int bias_lo;              // the bias partials are (hi, lo) float pairs of a double sum; the lo words sit lo_off floats behind `part`
+  unsigned long long lo_off;//   (the direct kernel: the discriminator's bias gradients are differences of nearly equal sums, srk_wgrad.hip)
   WProb prob[MAX_PROB];
   unsigned char c_prob[MAX_CHUNK], c_cy[MAX_CHUNK], c_cz[MAX_CHUNK];
 };

@@ -178,6 +178,14 @@ class GeneratorEngine:
             return
         self._works.append(dist.all_reduce(self._flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
+    def abandon_iteration(self):
+        """After a chain fault (train.Stepper.recover_chain_fault; the device is idle): forget what the interrupted iteration left behind.
+        Every buffer of an iteration lives in its autograd node; what the engine itself holds are the handles of bucket all-reduces
+        and the per-geometry sign-bit decisions, which depend on which kernel form a sequence takes (the chain forms now rest)."""
+        self._works = []
+        self._signs_bytes = {}
+        self._graphs = {}
+
     def _finish_reduce(self):
         self._join_side()
         for w in self._works:          # (the current = main stream waits for every bucket)
@@ -388,17 +396,21 @@ class GeneratorEngine:
                           alpha=INNER_RES_SCALE * rs, r1=View(D, 0, F_), beta1=rs, r2=outer_x, beta2=1.0)))
         # sign bits of the outputs of convs 1-4 for the block's data-gradient convolutions (1 MB per conv instead of the 16.8 / 33.5 MB
         # slice), where this sequence's launches offer them (16-bit storage: always; fp32: when it goes out as a chain kernel)
-        signs = None
+        signs, tag = None, 0
         if save and self.sign_bits and not self.use_graphs:
-            key = ("f", N, H, W, F_, self.precision, calls[0][1].fmt)
-            nb = self._signs_bytes.get(key)
-            if nb is None:
-                nb = self._signs_bytes[key] = L.conv_seq_signs_bytes(calls)
+            # (decided once per geometry, precision and DISPATCH GENERATION: _lib.dispatch_gen moves whenever a switch that changes the
+            # kernel form of a launch is thrown -- debug setters, a recovered chain fault)
+            key = ("f", N, H, W, F_, self.precision, calls[0][1].fmt, L.dispatch_gen)
+            ent = self._signs_bytes.get(key)
+            if ent is None:
+                ent = self._signs_bytes[key] = L.conv_seq_signs(calls)
+            nb, tag = ent
             if nb > 0:
                 signs = torch.empty(4, nb, dtype=torch.uint8, device=D.device)
                 for k in range(4):
                     calls[k][4]["signs_out"] = signs[k]
-        D._srk_signs = signs
+        # the layout tag travels with the bits: the data-gradient sequence reads them only if ITS launches use the same layout
+        D._srk_signs, D._srk_signs_tag = signs, tag
         L.conv3x3_seq(calls)
 
     def _drb_backward(self, d, pk: DrbPack, D, E, gx_out: View, geo, beta_self: float, outer_g: Optional[View], grads: Dict):
@@ -421,12 +433,12 @@ class GeneratorEngine:
             if not use_signs:
                 break
             # (fp32: only the chain form of THIS sequence reads sign bits; decided once per geometry)
-            key = ("b", N, H, W, F_, self.precision, calls[0][1].fmt)
-            ok = self._signs_bytes.get(key)
-            if ok is None:
-                ok = self._signs_bytes[key] = L.conv_seq_signs_bytes(calls + [(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out,
-                                                                               dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_))])
-            if ok > 0:
+            key = ("b", N, H, W, F_, self.precision, calls[0][1].fmt, L.dispatch_gen)
+            ent = self._signs_bytes.get(key)
+            if ent is None:
+                ent = self._signs_bytes[key] = L.conv_seq_signs(calls + [(View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out,
+                                                                          dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_))])
+            if ent[0] > 0 and ent[1] == getattr(D, "_srk_signs_tag", 0) and ent[0] == signs.shape[1]:
                 break
         calls.append((View(E, 0, 5 * F_), self.wb(pk.bwd[0]), None, gx_out, dict(N=N, H=H, W=W, OH=H, OW=W, Cin=5 * F_, Cout=F_,
                       r1=View(E, 0, F_), beta1=beta_self, r2=outer_g, beta2=1.0)))

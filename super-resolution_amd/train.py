@@ -60,6 +60,21 @@ class _AllReduceMean(torch.autograd.Function):
         return g / dist.get_world_size()
 
 
+def _ranks_share_a_gpu(device) -> bool:
+    """True if two ranks of the job run on the same physical GPU (same host, same device UUID / PCI address)."""
+    import socket
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or device is None or torch.device(device).type != "cuda":
+        return False
+    pr = torch.cuda.get_device_properties(torch.device(device))
+    ident = getattr(pr, "uuid", None)
+    ident = str(ident) if ident is not None else "/".join(str(getattr(pr, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    mine = (socket.gethostname(), ident)
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine, group=_stat_group())
+    return len(set(everyone)) < len(everyone)
+
+
 def _uses(stream, *tensors):
     """Tell the caching allocator that ``tensors`` (allocated on another stream) are read or written by work queued on ``stream``:
     a block freed on its home stream is then not handed out again before that work has run.  Every tensor that crosses between the
@@ -125,6 +140,16 @@ class Stepper:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         if distributed:
             _stat_group()          # (created by every rank at the same point)
+            # census bound of the chain forms (include/srk.h): a collective's kernel holds CUs while a peer rank is late -- seconds in a
+            # first iteration -- and a chain launch behind it has to wait that out; giving up after 50 ms would end the job (see step())
+            if "SRK_CHAIN_ENTRY_MS" not in os.environ and torch.device(device).type == "cuda":
+                L.lib().srk_chain_set_entry_us(30_000_000)
+            self.shared_gpu = _ranks_share_a_gpu(device)
+            if self.shared_gpu:
+                # The chain forms need the whole GPU: two ranks' 256-tile persistent launches would split the CUs and both give up at
+                # their census, every time.  (Rehearsals of several ranks on one card: tests/test_dp_gpu.py, bench.py with gloo.)
+                L.lib().srk_debug_set_h16_chain(0)
+                L.lib().srk_debug_set_w42_chain(0)
         self.last = {}
         self._grad_scaler = None      # fp16 activation storage (engine.precision == "fp16"): dynamic loss scaling, created on first use
         # The two discriminators run on two streams (133.4 vs 135.3 ms per iteration) and the D phase beside the generator's backward
@@ -185,9 +210,37 @@ class Stepper:
         sc.update()
 
     def step(self, imgs_lr, imgs_hr):
-        if self.workload == "g_only":
-            return self.warmup_step(imgs_lr, imgs_hr)
-        return self.gan_step(imgs_lr, imgs_hr)
+        """One iteration.  A dense block's convolutions may go out as ONE persistent launch (the chain forms, include/srk.h), which needs
+        every workgroup of that launch resident at once.  If one gave up -- a foreign process on the GPU, a kernel holding CUs beyond
+        the census bound -- the library has stored nothing from it, every optimizer step since has skipped itself on the device, and
+        the first library call that notices raises ChainTimeout: recover (device-wide wait, fault cleared, chain forms rested) and run
+        the iteration again, conv by conv.  What iterations in between returned as losses is undefined; weights and optimizer state
+        are those of the last good iteration (a discriminator whose step ran beside the failing launch may see this batch twice)."""
+        for attempt in range(3):
+            try:
+                if self.workload == "g_only":
+                    return self.warmup_step(imgs_lr, imgs_hr)
+                return self.gan_step(imgs_lr, imgs_hr)
+            except L.ChainTimeout:
+                # data parallel: the other ranks are inside this iteration's collectives; a rank that started over on its own would
+                # pair its all-reduces with the wrong ones.  There the census bound is 30 s (below), so this is a fault, not a busy GPU.
+                if attempt == 2 or self.distributed:
+                    raise
+                self.recover_chain_fault()
+        raise AssertionError("unreachable")
+
+    def recover_chain_fault(self):
+        """After ChainTimeout: wait for everything queued, clear the fault, drop the half-built state of the interrupted iteration."""
+        torch.cuda.synchronize()
+        code = L.chain_recover()
+        self.chain_recoveries = getattr(self, "chain_recoveries", 0) + 1
+        self.optimizer_G.zero_grad(set_to_none=True)
+        for opt in self.optimizer_D.values():
+            opt.zero_grad(set_to_none=True)
+        eng = getattr(self.generator, "_engine", None)
+        if eng is not None and hasattr(eng, "abandon_iteration"):
+            eng.abandon_iteration()
+        return code
 
     def loss_scalars(self, out):
         """Python floats of one iteration's losses under the reference's loss_dict names (esrgan.py:355), fetched

@@ -193,3 +193,214 @@ def test_wino42_offers_no_sign_bits(U):
     cs = [(x, wp, b, y, dict(kw, signs_out=signs[k]) if k < 4 else kw) for k, (x, wp, b, y, kw) in enumerate(calls)]
     with pytest.raises(RuntimeError):
         L.conv3x3_seq(cs)
+
+
+# ----------------------------------------------------------------------------------------------- protocol (round 4): census, wrap, recovery
+@pytest.fixture
+def _protocol_reset(U):
+    """every protocol test leaves the device as it found it: no fault, no back-off, default census bound, epoch 0"""
+    yield
+    L = U.L
+    torch.cuda.synchronize()
+    L.lib().srk_debug_chain_inject_fault(0)
+    L.chain_recover()
+    L.lib().srk_debug_chain_set(0, 0)
+    L.lib().srk_chain_set_entry_us(0)
+
+
+def test_chain_epoch_wrap_reset_is_invisible(U, _protocol_reset):
+    """flags hold `epoch + k + 1` in 32 bits and are compared as differences; before the epoch passes 2^30 the library zeroes flags and
+    census count on the launching stream (srk_chain_epoch_plan).  Start 7 convs short of the wrap and chain 12 blocks across it: bit-identical
+    results, exactly one reset."""
+    L = U.L
+    D, out, calls, keep = _block(U, 2, 64, 48, False, 1234)
+    L.lib().srk_debug_set_w42_chain(0)
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    refD, refO = D.clone(), out.clone()
+    L.lib().srk_debug_set_w42_chain(1)
+    L.lib().srk_debug_chain_set((1 << 30) - 7, 0)
+    r0 = L.chain_stats()["resets"]
+    for rep in range(12):
+        D[..., F_:] = 0
+        out.zero_()
+        L.conv3x3_seq(calls)
+        torch.cuda.synchronize()
+        assert torch.equal(D, refD) and torch.equal(out, refO), rep
+    assert L.chain_stats()["resets"] == r0 + 1
+
+
+@pytest.mark.parametrize("kind", ["w42", "h16"])
+def test_chain_census_gives_up_before_touching_memory_then_recovers(U, kind, _protocol_reset):
+    """A full-chip chain launch (256 tiles) behind a kernel that holds 64 CUs for 30 ms, with the census bound at 0.5 ms: not every
+    workgroup becomes resident in time, so the launch must give up as a whole -- NOTHING stored (the outputs keep their sentinel), the
+    fault word set, the next sequence call refused with ChainTimeout, optimizer steps skipped; after chain_recover the sequence runs (conv
+    by conv while the forms rest) and gives the reference result."""
+    L = U.L
+    if kind == "w42":
+        D, out, calls, keep = _block(U, 32, 64, 64, False, 4321)
+        setter = L.lib().srk_debug_set_w42_chain
+    else:
+        import test_h16_gpu as H
+        D, out, calls, keep = H._dense_block_calls(U, 7, 8, 128, 128, False, 77)
+        setter = L.lib().srk_debug_set_h16_chain
+    setter(0)
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    refD, refO = D.clone(), out.clone()
+    setter(1)
+    assert "chain_kernel" in _seq_kernel(L, calls)
+    D[..., F_:] = 7.0
+    out.fill_(7.0)
+    sentD, sentO = D.clone(), out.clone()
+    L.lib().srk_chain_set_entry_us(500)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    L.check(L.lib().srk_debug_hold_cus(64, 30000, side.cuda_stream), "srk_debug_hold_cus")
+    L.conv3x3_seq(calls)                      # (launched while the holder occupies its CUs: the census cannot complete within 0.5 ms)
+    torch.cuda.synchronize()
+    assert torch.equal(D, sentD) and torch.equal(out, sentO), "a launch that gave up at its census has stored something"
+    with pytest.raises(L.ChainTimeout):
+        L.conv3x3_seq(calls)
+    # an optimizer step while the fault is pending: refused on the host ...
+    p = torch.ones(1000, device="cuda"); g = torch.ones(1000, device="cuda")
+    step = torch.zeros((), device="cuda"); skip = torch.zeros((), device="cuda")
+    with pytest.raises(L.ChainTimeout):
+        L.adam_count_step(step, None, skip)
+    assert L.chain_recover() == 1
+    st = L.chain_stats()
+    assert st["strikes"] >= 1 and st["off_calls"] > 0
+    assert _seq_kernel(L, calls) == ""        # resting: conv by conv
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    if kind == "w42":
+        assert torch.equal(D, refD) and torch.equal(out, refO)
+    else:
+        assert torch.equal(D.float(), refD.float()) and torch.equal(out.float(), refO.float())
+    # ... and the forms come back once the rest is over
+    L.lib().srk_debug_chain_set(0, 0)
+    L.lib().srk_chain_set_entry_us(0)
+    assert "chain_kernel" in _seq_kernel(L, calls)
+    D[..., F_:] = 0
+    out.zero_()
+    L.conv3x3_seq(calls)
+    torch.cuda.synchronize()
+    if kind == "w42":
+        assert torch.equal(D, refD) and torch.equal(out, refO)
+
+
+def test_adam_skips_itself_on_the_device_while_a_chain_fault_is_pending(srk, U, _protocol_reset):
+    """The host may be iterations ahead of the GPU when a chain launch gives up: the optimizer steps it has ALREADY queued must not touch
+    the weights.  The fault is raised here from the device side of the stream (in stream order behind a 20 ms kernel), after the host has
+    queued the step: parameters, moments and step counter stay as they were; after recovery the same step goes through."""
+    L = U.L
+    optim = __import__("importlib").import_module("super-resolution_amd.optim")
+    # (make sure the fault word exists: one chain launch)
+    D, out, calls, keep = _block(U, 1, 32, 16, False, 5)
+    L.conv3x3_seq(calls)
+    ps = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (5000, 300, 70000)]
+    opt = optim.Adam(ps, lr=1e-2)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()                                  # a normal first step (allocates the state)
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in ps]
+    m_before = [opt.state[p]["exp_avg"].clone() for p in ps]
+    s = torch.cuda.current_stream()
+    L.check(L.lib().srk_debug_hold_cus(4, 20000, s.cuda_stream), "hold")
+    L.check(L.lib().srk_debug_chain_inject_fault_async(s.cuda_stream), "inject")
+    opt.step()                                  # host-side checks pass (the word is still clear); on the device the fault precedes it
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps))
+    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(m_before, ps))
+    assert float(opt.param_groups[0]["_srk_step"]) == 1.0
+    with pytest.raises(L.ChainTimeout):
+        opt.step()
+    assert L.chain_recover() != 0
+    opt.step()
+    torch.cuda.synchronize()
+    assert not any(torch.equal(a, p.detach()) for a, p in zip(before, ps))
+    assert float(opt.param_groups[0]["_srk_step"]) == 2.0
+
+
+def test_stepper_repeats_an_iteration_whose_chain_launch_gave_up(srk, U, _protocol_reset):
+    """train.Stepper.step: a ChainTimeout in the middle of an iteration (here: injected behind the forward, in front of the first weight
+    gradient) -> recover, run the iteration again conv by conv.  fp32 chain and conv-by-conv results are bit-identical, so the weights
+    after the repaired iteration must EQUAL those of an undisturbed Stepper bit for bit (esrgan.py:416-427)."""
+    import importlib
+    from oracle import esrgan_oracle as O
+    train = importlib.import_module("super-resolution_amd.train")
+    L = U.L
+    lr, hr = O.jet_images(16, 1, 256, 256, 3, 4)
+
+    def mk():
+        torch.manual_seed(0)
+        return train.Stepper(workload="g_only", res_blocks=1, filters=64, device=torch.device("cuda"), hr=256, factor=4, res_scale=0.2)
+    ref = mk()
+    for _ in range(2):
+        out_ref = ref.step(lr.cuda(), hr.cuda())
+    torch.cuda.synchronize()
+    st = mk()
+    st.step(lr.cuda(), hr.cuda())
+    assert L.chain_stats()["launches"] > 0, "this geometry was meant to run the chain form"
+    orig = L.conv3x3_wgrad_batched
+    fired = []
+
+    def faulty(*a, **kw):
+        if not fired:
+            fired.append(1)
+            L.lib().srk_debug_chain_inject_fault(1)
+        return orig(*a, **kw)
+    L.conv3x3_wgrad_batched = faulty
+    try:
+        out = st.step(lr.cuda(), hr.cuda())
+    finally:
+        L.conv3x3_wgrad_batched = orig
+    torch.cuda.synchronize()
+    assert fired and getattr(st, "chain_recoveries", 0) == 1
+    assert torch.equal(out["g_loss"], out_ref["g_loss"])
+    for (k, a), (_, b) in zip(st.generator.state_dict().items(), ref.generator.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_two_full_size_chain_launch_streams_from_two_host_threads(U, _protocol_reset):
+    """At most ONE chain kernel may be in flight per device (two full-chip persistent kernels would each hold part of the CUs and fail
+    their census).  Two host threads, each with its own stream and its own dense block at the full trunk geometry (32 x 64 x 64 = 256
+    tiles), launch 10 chains each at the same time: the library orders the launches by events; every result is the reference, and no
+    launch gives up."""
+    import threading
+    L = U.L
+    blocks = [_block(U, 32, 64, 64, bool(i), 2000 + i) for i in range(2)]
+    refs = []
+    L.lib().srk_debug_set_w42_chain(0)
+    for D, out, calls, keep in blocks:
+        L.conv3x3_seq(calls)
+        torch.cuda.synchronize()
+        refs.append((D.clone(), out.clone()))
+    L.lib().srk_debug_set_w42_chain(1)
+    n0 = L.chain_stats()["launches"]
+    errs = []
+
+    def worker(i):
+        try:
+            D, out, calls, keep = blocks[i]
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for rep in range(10):
+                    D[..., F_:] = 0
+                    out.zero_()
+                    L.conv3x3_seq(calls)
+                    s.synchronize()
+                    if not (torch.equal(D, refs[i][0]) and torch.equal(out, refs[i][1])):
+                        errs.append((i, rep, "mismatch"))
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, repr(e)))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    st = L.chain_stats()
+    assert st["launches"] == n0 + 20 and st["strikes"] == 0

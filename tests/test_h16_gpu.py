@@ -551,6 +551,55 @@ def test_h16_configs4_full_architecture_forward_and_gradients_vs_oracle(srk, mod
     assert worst[1] < gtol, (mode, worst)
 
 
+@pytest.mark.parametrize("mode", ["fp16", "bf16s"])
+def test_h16_configs4_batch8_launch_set_vs_oracle(srk, mode):
+    """BASELINE configs[4]'s ACTUAL launch set: batch 8 of 3 x 128 x 128 (256 sixteen-row tiles = one per CU) on GeneratorRRDB(3, 64, 2,
+    num_upsample=2), default dispatch.  At this size every dense block's forward and data-gradient sequence goes out as ONE
+    conv3x3_h16_chain_kernel launch and its five weight gradients as the LOADER form of wgrad_h16_kernel (both only selected at >= 200
+    tiles / >= 8 tiles per workgroup, which the batch-1 test above never reaches): asserted from the names the C side reports for the
+    launches of this very forward / backward (srk_conv3x3_seq_kernel_name, srk_conv3x3_wgrad_kernel_name).  Forward and EVERY weight / bias
+    gradient vs the CPU fp32 oracle (models.py:34-41,58,63,99, esrgan.py:416-427; ~15 s of CPU) at the full-architecture bounds."""
+    L = srk._lib
+    R = 2
+    gen = srk.GeneratorRRDB(3, filters=64, num_res_blocks=R, num_upsample=2).cuda()
+    sd = O.default_init_generator(3, channels=3, filters=64, num_res_blocks=R, num_upsample=2)
+    gen.load_state_dict(sd)
+    g = torch.Generator().manual_seed(99)
+    hr = torch.rand(8, 3, 512, 512, generator=g)
+    lr = torch.nn.functional.avg_pool2d(hr, 4)
+    sdo = {k: (v.clone().requires_grad_(True) if k not in ("power", "multiplier") else v) for k, v in sd.items()}
+    yo, _ = O.generator_forward(sdo, lr, R, 2, 0.2, training=True)
+    O.warmup_loss(yo, hr).backward()
+    gen._engine.precision = mode
+    tname = "_Float16" if mode == "fp16" else "__bf16"
+    L.KernelTimer.start()
+    try:
+        y = gen(lr.cuda())
+        otol, gtol = FULL_TOL[mode]
+        err = _mrel(y.detach().cpu(), yo.detach())
+        scale = 65536.0 if mode == "fp16" else 1.0
+        ((y - hr.cuda()).abs().mean() * scale).backward()
+    finally:
+        ran = L.KernelTimer.stop()
+    # ---- what ran: 3 R forward + 3 R data-gradient chain launches, 3 R loader-form batched weight gradients
+    chain = f"conv3x3_h16_chain_kernel<{tname}>"
+    loader = f"wgrad_h16_kernel<{tname}, 0, true, 8>+reduce"
+    assert chain in ran and ran[chain]["n"] == 6 * R, sorted(ran)
+    assert loader in ran and ran[loader]["n"] >= 3 * R, sorted(ran)
+    # (nothing of the trunk fell back to one-conv launches: what is left outside the chains are conv1, conv2, two upsampling convs and
+    # conv3.0 / conv3.2, forward and data gradient)
+    single = sum(v["n"] for k, v in ran.items() if k.startswith("conv3x3_h16") and not k.startswith("conv3x3_h16_chain"))
+    assert single <= 12, sorted(ran)
+    assert err < otol, (mode, err)
+    named = dict(gen.named_parameters())
+    errs = {k: _mrel(p.grad.cpu() / scale, sdo[k].grad) for k, p in named.items() if p.grad is not None}
+    assert len(errs) == sum(1 for k in sd if k not in ("power", "multiplier"))          # every weight and bias of the model
+    assert all(torch.isfinite(p.grad).all() for p in named.values() if p.grad is not None)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print(mode, "batch 8 forward", err, "worst gradient", worst)
+    assert worst[1] < gtol, (mode, worst)
+
+
 def test_h16_warmup_step_with_loss_scaling_matches_oracle_update(srk):
     """train.Stepper in the fp16 mode: dynamic loss scaling (GradScaler) around the generator's backward; two warm-up iterations
     (esrgan.py:416-427) move the weights like the oracle's Adam does, and the scale stays at its initial 2^16 (no overflow)."""

@@ -400,14 +400,22 @@ def test_full_size_gan_step_batch32_vs_oracle_and_schedule_bit_identity():
         assert abs(loss_D.item() - lD.item()) < 1e-3 * abs(lD.item())
         st.discriminators[k].zero_grad()
         loss_D.backward()
-        # per tensor: 2e-2 (such sums: first-layer weights 4.4e-3, a mid-layer bias 1.0e-2 measured, float32 CPU 2-8e-3) or 1.5 x the
-        # reference arithmetic's own distance; over ALL of the discriminator's gradients together (relative L2): 5e-3
+        # per tensor: 5e-3, or 1.5 x the reference arithmetic's (CPU float32) own distance from the float64 result where that is larger.
+        # (Round 3 needed 2e-2 here: a mid-layer BIAS gradient sat 1.0e-2 away where CPU float32 sits 2.2e-3 away.  These gradients are
+        # differences of nearly equal sums over 2 M pixels -- real minus fake pass --, and the direct weight-gradient kernel summed dy in
+        # float32, 128 terms in a row per lane.  Since round 4 the bias path runs in double end to end and the pixel-split partials of
+        # weights and biases are added in double: csrc/srk_wgrad.hip.)  Over ALL of the discriminator's gradients (relative L2): 5e-3.
         num = den = 0.0
+        table = []
         for n, q in st.discriminators[k].named_parameters():
-            bound = max(2e-2, 1.5 * rel(d32[n].grad.double(), dk[n].grad))
-            assert rel(q.grad.cpu().double(), dk[n].grad) < bound, (k, n, bound)
+            cpu32 = rel(d32[n].grad.double(), dk[n].grad)
+            mine = rel(q.grad.cpu().double(), dk[n].grad)
+            table.append((n, mine, cpu32, max(5e-3, 1.5 * cpu32)))
             num += (q.grad.cpu().double() - dk[n].grad).square().sum().item()
             den += dk[n].grad.square().sum().item()
+        print(f"D{k} gradients vs float64 (HIP, CPU float32, bound):", [(n, f"{a:.2e}", f"{b:.2e}", f"{c:.2e}") for n, a, b, c in table])
+        for n, mine, cpu32, bound in table:
+            assert mine < bound, (k, n, mine, cpu32, bound)
         assert (num / den) ** 0.5 < 5e-3, (k, (num / den) ** 0.5)
     del params, y, srs, dref, lG, loss_G, generated, gt
     # ---- schedules: overlap on / off, two whole iterations each, same fixed epsilons
