@@ -144,6 +144,9 @@ int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
 int srk_conv3x3_seq_kernel_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_debug_set_h16_chain(int mode);
 int srk_debug_set_w42_chain(int mode);
+/* MFMA shape of the 16-bit chain kernel: 1 (default; SRK_H16_CHAIN_M16) = v_mfma_f32_16x16x32 with the weights as the row operand and an
+ * epilogue that stores straight from the accumulators; 0 = the 32x32x16 form (A/B measurements, tests) */
+int srk_debug_set_h16_chain_m16(int on);
 /* pending fault code (1: census, 2: flag wait; 0: none) after waiting for the device, cleared; < 0: error.  See above. */
 int srk_chain_recover(void);
 /* chain launches so far / wrap resets of the flag epoch / recovered time-outs / sequence calls left in the back-off (any may be NULL) */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SRK_LIB_PATH", os.path.join(_HERE, "libsrk.so"))   # 
 IN_PLAIN, IN_UNSHUFFLE, IN_ZERO_UPSAMPLE = 0, 1, 2
 
 EXPORTS = [
-    "srk_conv3x3_signs_bytes", "srk_conv3x3_seq_signs_bytes", "srk_conv3x3_seq_signs_tag", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_debug_set_wgrad_w22_form", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
+    "srk_conv3x3_signs_bytes", "srk_conv3x3_seq_signs_bytes", "srk_conv3x3_seq_signs_tag", "srk_adam_plan", "srk_adam_step", "srk_adam_step_small", "srk_conv3x3", "srk_conv3x3_seq", "srk_conv3x3_seq_kernel_name", "srk_debug_set_h16_chain", "srk_debug_set_h16_chain_m16", "srk_debug_set_w42_chain", "srk_conv3x3_kernel_name", "srk_debug_set_conv_small", "srk_debug_set_wino42_nmt", "srk_debug_set_wgrad_w22_form", "srk_conv3x3_wgrad", "srk_conv3x3_wgrad_workspace", "srk_conv3x3_wgrad_batched",
     "srk_conv3x3_wgrad_batched_workspace", "srk_conv3x3_wgrad_seq", "srk_conv3x3_wgrad_kernel_name", "srk_pack_plan", "srk_pack_weights",
     "srk_pack_weights_bf16x3", "srk_pack_weights_h16", "srk_packed_floats_h16", "srk_debug_set_h16_mt", "srk_conv3x3_bf16x3_supported", "srk_packed_floats", "srk_packed_floats_wino", "srk_packed_floats_wino4", "srk_packed_floats_wino42", "srk_pixel_shuffle_fwd", "srk_pixel_shuffle_bwd", "srk_nchw_to_nhwc", "srk_nhwc_to_nchw",
     "srk_sum_pool_fwd", "srk_sum_pool_bwd", "srk_workspace_bytes", "srk_conv3x3_fwd", "srk_conv3x3_dgrad", "srk_conv3x3_wgrad_flat",
@@ -171,7 +171,8 @@ def lib():
         L.srk_adam_count_step.argtypes = [_fp, _fp, _fp, _fp]
         # whatever changes which kernel form a launch takes bumps dispatch_gen: callers that cache a dispatch-dependent answer (the engine's
         # sign-bit decisions) key it with the generation
-        for name in ("srk_debug_set_h16_mt", "srk_debug_set_h16_chain", "srk_debug_set_w42_chain", "srk_debug_set_wino42_nmt",
+        L.srk_debug_set_h16_chain_m16.argtypes = [C.c_int]
+        for name in ("srk_debug_set_h16_mt", "srk_debug_set_h16_chain", "srk_debug_set_h16_chain_m16", "srk_debug_set_w42_chain", "srk_debug_set_wino42_nmt",
                      "srk_chain_recover", "srk_debug_chain_set"):
             setattr(L, name, _bumping(getattr(L, name)))
         _lib = L

@@ -1092,6 +1092,7 @@ int srk_conv_h16_mt(const srk_conv_args& a);
 int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st);   // 1: launched as one chain kernel, 0: not eligible, < 0: error
 unsigned srk_chain_fault();          // (srk_chain.h) != 0 while a chain launch's time-out is pending
 int srk_conv_h16_chain_would(const srk_conv_args* args, int n);
+int srk_conv_h16_chain_m16();
 int srk_conv_h16_chain_name(const srk_conv_args* args, int n, char* buf, size_t len);
 int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st);   // the same for the fp32 F(2x4,3x3) kernel (wp_format 6)
 int srk_conv_w42_chain_would(const srk_conv_args* args, int n);
@@ -1228,7 +1229,7 @@ extern "C" int srk_conv3x3_seq_signs_tag(const srk_conv_args* args, int n) {
   const int fmt = args[0].wp_format;
   if (fmt == 7 || fmt == 8) {
     int rows;
-    if (n >= 2 && srk_conv_h16_chain_would(args, n) == 1) rows = 16;
+    if (n >= 2 && srk_conv_h16_chain_would(args, n) == 1) rows = 16 | (srk_conv_h16_chain_m16() ? 0x40 : 0);      // (the 16x16x32 form: a layout of its own)
     else { const int mt = srk_conv_h16_mt(args[0]); rows = mt == 1 ? 8 : 4 * mt; }
     return rows | (fmt << 8);
   }

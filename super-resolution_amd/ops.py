@@ -14,6 +14,8 @@ pre-activations, conv(lrelu(z_prev)), so every node only needs its own input and
 """
 import os
 
+import threading
+
 import torch
 
 from . import _lib as L
@@ -150,6 +152,7 @@ class ConvPre(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.in_slope, ctx.has_b = stride, in_slope, b is not None
         ctx.wp, ctx.wpt = wp, wpt
+        ctx.want_pg = _want_param_grads()
         return conv_pre_raw(x, w, b, stride, in_slope, wp)
 
     @staticmethod
@@ -161,7 +164,7 @@ class ConvPre(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ConvDgrad.apply(dz, w, x, ctx.stride, ctx.in_slope, ctx.wp, ctx.wpt)
-        if (not SKIP_PARAM_GRADS) and (ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])):
+        if ctx.want_pg and (ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])):
             dw, db = ConvWgrad.apply(x, dz, ctx.stride, ctx.in_slope)
             if not ctx.has_b:
                 db = None
@@ -224,10 +227,31 @@ class ConvWgrad(torch.autograd.Function):
         return g_x, g_dz, None, None
 
 
-# Set by train.Stepper.d_phase_loss around the gradient penalty's INNER torch.autograd.grad(pred_hat, x_hat, create_graph=True)
-# (esrgan.py:602-605): that call wants the input gradient only, but a custom Function's ctx.needs_input_grad is static, so the
-# backward below would also launch every layer's weight gradient and throw it away (18 launches per iteration).
-SKIP_PARAM_GRADS = False
+# The gradient penalty's INNER torch.autograd.grad(pred_hat, x_hat, create_graph=True) (esrgan.py:602-605) wants the input gradient only,
+# but a custom Function's ctx.needs_input_grad is static: the backward below would also launch every layer's weight gradient and throw
+# it away (18 launches per iteration).  train.Stepper.d_phase_loss therefore builds the x_hat FORWARD under input_grad_only(): the nodes
+# created inside it carry the decision themselves (ctx.want_pg), so nothing global is read while some other backward -- a second
+# Stepper, another host thread, a re-entrant backward through the same Functions -- is running on the autograd threads.  (Round 3 used a
+# module-global flag around the inner grad call: any backward running concurrently silently lost its weight gradients.)
+_tls = threading.local()
+
+
+class input_grad_only:
+    """Forward passes built inside this context produce nodes whose backward returns the INPUT gradient only (no weight / bias
+    gradients).  Thread-local, captured at forward time."""
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "param_grads", True)
+        _tls.param_grads = False
+        return self
+
+    def __exit__(self, *exc):
+        _tls.param_grads = self._prev
+        return False
+
+
+def _want_param_grads() -> bool:
+    return getattr(_tls, "param_grads", True)
 
 
 class ChainPre(torch.autograd.Function):
@@ -257,6 +281,7 @@ class ChainPre(torch.autograd.Function):
             H, W, Ci = OH, OW, Co
         L.conv3x3_seq(calls)
         ctx.meta = meta
+        ctx.want_pg = _want_param_grads()
         ctx.save_for_backward(*zs[:-1], *[wb[2 * l] for l in range(n_l)])
         ctx.has_b = [wb[2 * l + 1] is not None for l in range(n_l)]
         return zs[-1]
@@ -270,7 +295,7 @@ class ChainPre(torch.autograd.Function):
         zs, ws = saved[:n_l], saved[n_l:]
         dz = dz.contiguous()
         grads = [None] * (2 * n_l)
-        want_w = [(not SKIP_PARAM_GRADS) and (ctx.needs_input_grad[2 + 2 * l] or (ctx.has_b[l] and ctx.needs_input_grad[3 + 2 * l]))
+        want_w = [ctx.want_pg and (ctx.needs_input_grad[2 + 2 * l] or (ctx.has_b[l] and ctx.needs_input_grad[3 + 2 * l]))
                   for l in range(n_l)]
         if not torch.is_grad_enabled():
             # first-order backward (nothing will differentiate THIS pass): no autograd nodes needed, so the whole chain of data

@@ -390,13 +390,11 @@ class Stepper:
             if epsilon is None:
                 epsilon = torch.rand(n_img, 1, 1, 1, device=gt.device)
             x_hat = (epsilon * gt + (1 - epsilon) * gen_detached).requires_grad_(True)
-            pred_hat = D(x_hat, cond)
-            # (only the INPUT gradient is asked for: the convolution nodes skip their weight gradients, ops.SKIP_PARAM_GRADS)
-            ops.SKIP_PARAM_GRADS = True
-            try:
-                (grad_hat,) = torch.autograd.grad(pred_hat, x_hat, grad_outputs=valid, create_graph=True, retain_graph=True)
-            finally:
-                ops.SKIP_PARAM_GRADS = False
+            # (only the INPUT gradient of this pass is ever asked for -- pred_hat enters the loss through grad_hat alone --: its nodes are
+            # built to skip their weight gradients, ops.input_grad_only)
+            with ops.input_grad_only():
+                pred_hat = D(x_hat, cond)
+            (grad_hat,) = torch.autograd.grad(pred_hat, x_hat, grad_outputs=valid, create_graph=True, retain_graph=True)
             grad_norm = grad_hat.reshape(n_img, -1).norm(2, dim=1)
             gp = (grad_norm - 1).square().mean() * (self.lambda_reg / 2)
             loss_D = loss_D + gp

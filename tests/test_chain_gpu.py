@@ -271,6 +271,8 @@ def test_chain_census_gives_up_before_touching_memory_then_recovers(U, kind, _pr
     st = L.chain_stats()
     assert st["strikes"] >= 1 and st["off_calls"] > 0
     assert _seq_kernel(L, calls) == ""        # resting: conv by conv
+    D[..., F_:] = 0
+    out.zero_()
     L.conv3x3_seq(calls)
     torch.cuda.synchronize()
     if kind == "w42":
