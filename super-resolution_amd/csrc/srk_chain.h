@@ -10,8 +10,8 @@
 //     (srk_chain_census_*: one atomic add per workgroup on a device word, then a bounded wait -- SRK_CHAIN_ENTRY_MS, 50 ms -- until
 //     the count has reached the launch's target).  If the grid is not resident by then (a foreign process on the GPU, a kernel of
 //     another stream holding CUs for longer than that) the launch gives up BEFORE any arithmetic has consumed unpublished data and
-//     before any store: the first workgroup to time out poisons the count word by compare-and-swap -- which can only succeed while
-//     the count is short of the target, so all workgroups reach the same verdict --, sets *err = 1 and every workgroup returns;
+//     before any store: the first workgroup to time out ORs a poison bit into the count word; the last arrival, which would have
+//     published "go", finds the bit and publishes nothing, so all workgroups reach the same verdict; *err = 1, every workgroup returns;
 //   * a tile publishes conv k before it waits for anybody's conv k (no cycle), and every flag wait is bounded as well
 //     (SRK_CHAIN_WAIT_TICKS = 30 s; with the census in front it can only trip on a fault): it sets *err = 2 and goes on, so the
 //     kernel always drains;
@@ -42,32 +42,65 @@ struct srk_chain_args {
   unsigned* arrive;            // census word (device, uncached): workgroups of all chain launches so far | SRK_CHAIN_POISON
   unsigned arrive_target;      // its value once every workgroup of THIS launch has counted itself in
   unsigned entry_ticks;        // bound of the census wait (100 MHz ticks)
+  unsigned skew_ticks;         // start skew: workgroup b begins (b >> 3) % skew_groups * skew_ticks late (srk_chain_skew), 0 = none
+  unsigned skew_groups;
 };
 
 #if defined(__HIPCC__)
+// ---- start skew.  Left alone, all tiles of a chain launch run in lockstep: every CU reaches a conv's epilogue within a microsecond of the
+// others, 16.8 MB (16-bit kernel; fp32: 33.5 MB) of write-through stores hit the memory system at once, and every wave sits in its store
+// instructions until HBM has taken the burst (stamps: 4.7 us per conv with NOTHING but eight fused multiply-adds and a store per item
+// left in the epilogue) while the matrix pipes idle.  Tiles that start a little apart stay apart (a tile that is ahead of its neighbours
+// does not wait for them until the last two stages of its next conv: slack of (nq - 2) stages), so their bursts land beside other
+// tiles' main loops.  Costs the skew once per launch.
+__device__ __forceinline__ void srk_chain_skew(const srk_chain_args& A) {
+  if (A.skew_ticks) {
+    const unsigned d = ((blockIdx.x >> 3) % A.skew_groups) * A.skew_ticks;       // (blockIdx.x >> 3: the workgroup's index inside its XCD)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)d) __builtin_amdgcn_s_sleep(4);
+  }
+}
+
 // ---- census: is every workgroup of this launch resident?  Called by ONE lane of the workgroup.
-// step 1, at kernel entry: count me in.  Returns false if an earlier launch has poisoned the word (the host has not recovered yet).
-__device__ __forceinline__ bool srk_chain_census_arrive(const srk_chain_args& A) {
+// Two words, 64 bytes apart: `arrive` is only ever touched by atomics (one add per workgroup; an OR when somebody gives up), `go`
+// (= arrive + 16) is stored ONCE per launch, by the last workgroup to arrive, and is what everybody polls.  (First version, one word:
+// 256 workgroups polling the word the late arrivals' atomic adds were queued on -- the polls starved the adds, and the census of the
+// fp32 kernels took 84-242 us instead of ~2: profiles/r04_ab_w42_census_first_version.txt.)
+// step 1, at kernel entry: count me in.  0 = an earlier launch has poisoned the word (give up), 1 = counted, 2 = counted as the LAST one
+// (the whole grid is resident; `go` has been published).
+__device__ __forceinline__ int srk_chain_census_arrive(const srk_chain_args& A) {
   const unsigned old = __hip_atomic_fetch_add(A.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return (old & SRK_CHAIN_POISON) == 0;
+  if (old & SRK_CHAIN_POISON) return 0;
+  if (old + 1u == A.arrive_target) {
+    __hip_atomic_store(A.arrive + 16, A.arrive_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 2;
+  }
+  return 1;
 }
 // step 2, before the workgroup's first store / first flag wait: true = all resident, go; false = give up (nothing touched so far).
-// The verdict is the same for every workgroup: the poison bit can only be set while the count is short of the target.
-__device__ __forceinline__ bool srk_chain_census_wait(const srk_chain_args& A) {
+// The verdict is the same for every workgroup: whoever times out ORs the poison bit into `arrive`; the OR returns the count as it was --
+// short of the target: the last arrival will find the bit and publish nothing, so nobody ever goes; at the target: everybody had arrived
+// (the bit came too late to matter) and `go` is on its way, keep waiting for it.
+__device__ __forceinline__ bool srk_chain_census_wait(const srk_chain_args& A, int arrived) {
+  if (arrived == 0) return false;
+  if (arrived == 2) return true;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
-    const unsigned w = __hip_atomic_load(A.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w & SRK_CHAIN_POISON) return false;
-    if (w == A.arrive_target) return true;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)A.entry_ticks) {
-      unsigned expect = w;
-      if (__hip_atomic_compare_exchange_strong(A.arrive, &expect, w | SRK_CHAIN_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+  bool timed_out = false;
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(A.arrive + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.arrive_target) return true;
+    if ((spins & 63u) == 63u && (__hip_atomic_load(A.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SRK_CHAIN_POISON)) {
+      // somebody gave up: unless everybody had arrived before that (then `go` is coming), so do I
+      if ((__hip_atomic_load(A.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~SRK_CHAIN_POISON) != A.arrive_target) return false;
+    }
+    if (!timed_out && __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)A.entry_ticks) {
+      timed_out = true;
+      const unsigned old = __hip_atomic_fetch_or(A.arrive, SRK_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((old & ~SRK_CHAIN_POISON) != A.arrive_target) {
         __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
       }
-      continue;            // (somebody arrived or poisoned in between: look again)
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(16);
   }
 }
 // The neighbour lane `lane` (0..8: dy = lane / 3 - 1, dx = lane % 3 - 1) of tile (n, ty, tx) watches; lanes that watch nothing read the
@@ -127,6 +160,8 @@ bool srk_chain_flags_uncached();           // the flag array is uncached memory 
 // `st` ordered behind the previous chain launch; call srk_chain_end afterwards), 0 = not now (stream capture, forms switched off or backing
 // off after a time-out), < 0 = error (SRK_ERR_CHAIN_TIMEOUT: an earlier launch timed out and srk_chain_recover has not been called)
 int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A);
+// start skew of a chain kernel kind ("H16" / "W42"): SRK_<kind>_CHAIN_SKEW_NS (per phase) and SRK_<kind>_CHAIN_SKEW_GROUPS (phases)
+void srk_chain_skew_of(const char* kind, unsigned dflt_ns, unsigned dflt_groups, srk_chain_args* A);
 int srk_chain_end(hipStream_t st, bool launched);
 // true while the chain forms rest after a recovered time-out (sequences go conv by conv); tick: this is a launch attempt, count it off
 bool srk_chain_resting(bool tick);

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int CHAIN_WORDS = SRK_CHAIN_FLAGS + 16;        // flags + the census word (its own 64 bytes), one uncached block
+constexpr int CHAIN_WORDS = SRK_CHAIN_FLAGS + 32;        // flags + the census count + its "go" word (64 bytes each), one uncached block
 struct ChainDev {
   unsigned* flags = nullptr;   // one word per tile (device), then the census word at [SRK_CHAIN_FLAGS]
   unsigned* err = nullptr;     // pinned host word a kernel writes when a wait ran into its time limit (1: census, 2: flag wait)
@@ -146,9 +146,22 @@ int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A) {
   }
   A->n = n; A->epoch = D->epoch; A->flags = D->flags; A->err = D->err;
   A->arrive = D->flags + SRK_CHAIN_FLAGS; A->arrive_target = D->arrive_base + (unsigned)tiles; A->entry_ticks = D->entry_ticks;
+  A->skew_ticks = 0; A->skew_groups = 1;
   D->epoch += (unsigned)n;
   D->arrive_base += (unsigned)tiles;
   return 1;
+}
+
+void srk_chain_skew_of(const char* kind, unsigned dflt_ns, unsigned dflt_groups, srk_chain_args* A) {
+  char name[64];
+  snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_NS", kind);
+  const char* e = getenv(name);
+  unsigned ns = e ? (unsigned)atoi(e) : dflt_ns;
+  snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_GROUPS", kind);
+  e = getenv(name);
+  unsigned g = e ? (unsigned)atoi(e) : dflt_groups;
+  if (g < 2 || g > 64 || ns > 100000) { ns = 0; g = 1; }
+  A->skew_ticks = ns / 10; A->skew_groups = g;
 }
 
 int srk_chain_end(hipStream_t st, bool launched) {

@@ -278,8 +278,29 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 // (n16 = lane & 15, G = lane >> 4) holds the 8 CONSECUTIVE channels 32 p + 8 G .. + 7 of pixel 16 ph + n16: item (m, ph, p) = one
 // 16-byte store, residual / mask loads likewise.  Sign bits: item (m, ph, p) = bits 8 (4 m + 2 ph + p) .. + 7 of the lane's 128
 // (a layout of this form only: srk_conv3x3_seq_signs_tag tells the forms apart).
+// The accumulators START at the bias (conv3x3_h16_chain_kernel stages it through the LDS), so the output is acc * alpha; and every scalar the
+// epilogue needs was fetched when the conv began (h16_epi_pre): stamps showed 1.9-2.2 us of a 4.8 us epilogue going to the argument loads
+// and the bias round trip, with the matrix pipes idle.
+struct h16_epi_pre {
+  const float *y, *r1, *r2, *mask;
+  void* signs;
+  int y_ldc, y_coff, r1_ldc, r1_coff, r2_ldc, r2_coff, m_ldc, m_coff, OH, OW, Cout, flags;
+  float alpha, beta1, beta2, slope, mask_slope;
+};
+__device__ __forceinline__ h16_epi_pre h16_epi_fetch(const srk_conv_args& a) {
+  h16_epi_pre e;
+  e.y = a.y; e.r1 = a.r1; e.r2 = a.r2; e.mask = a.mask; e.signs = a.signs;
+  e.y_ldc = a.y_ldc; e.y_coff = a.y_coff; e.r1_ldc = a.r1_ldc; e.r1_coff = a.r1_coff; e.r2_ldc = a.r2_ldc; e.r2_coff = a.r2_coff;
+  e.m_ldc = a.m_ldc; e.m_coff = a.m_coff; e.OH = a.OH; e.OW = a.OW; e.Cout = a.Cout; e.flags = a.flags;
+  e.alpha = a.alpha; e.beta1 = a.beta1; e.beta2 = a.beta2; e.slope = a.slope; e.mask_slope = a.mask_slope;
+  // (pinned in scalar registers HERE: left alone, the compiler loads each field where it is first used -- in the epilogue)
+  asm volatile("" : "+s"(e.y), "+s"(e.r1), "+s"(e.r2), "+s"(e.mask), "+s"(e.signs));
+  asm volatile("" : "+s"(e.y_ldc), "+s"(e.y_coff), "+s"(e.r1_ldc), "+s"(e.r1_coff), "+s"(e.r2_ldc), "+s"(e.r2_coff), "+s"(e.m_ldc), "+s"(e.m_coff));
+  asm volatile("" : "+s"(e.OH), "+s"(e.OW), "+s"(e.Cout), "+s"(e.flags), "+s"(e.alpha), "+s"(e.beta1), "+s"(e.beta2), "+s"(e.slope), "+s"(e.mask_slope));
+  return e;
+}
 template <typename T, int MT, int NS, int SAUX>
-__device__ __forceinline__ void h16_epilogue16(const srk_conv_args& a, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane, int tile) {
+__device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane, int tile, int cstamp = 0) {
   typedef typename H16<T>::v8 v8;
   h16_u32x4 sbits = {0u, 0u, 0u, 0u};
   const bool wsigns = (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = (a.flags & SRK_CONV_MASK_SIGNS) != 0;
@@ -287,26 +308,11 @@ __device__ __forceinline__ void h16_epilogue16(const srk_conv_args& a, f32x4 (&a
   if (msigns) sbits = *sgp;
   constexpr int TB = NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1);      // rows per batch (loads ahead of stores)
   const int n16 = lane & 15, G = lane >> 4;
-  float bq[2][8];
   bool cok[2];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int co = 32 * p + 8 * G;
-    cok[p] = co + 7 < a.Cout;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bq[p][e] = 0.f;
-    if (a.bias && cok[p]) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bq[p][e] = b0[e] * a.alpha; bq[p][4 + e] = b1[e] * a.alpha; }
-    }
-  }
-  const float* r1p = srk_sgpr_opaque(a.r1); const float* r2p = srk_sgpr_opaque(a.r2); const float* mkp = srk_sgpr_opaque(a.mask);
-  const bool has_r1 = r1p != nullptr, has_r2 = r2p != nullptr;
-  const int r1l = srk_sgpr_opaque(a.r1_ldc), r1c = srk_sgpr_opaque(a.r1_coff), r2l = srk_sgpr_opaque(a.r2_ldc), r2c = srk_sgpr_opaque(a.r2_coff);
-  const int mkl = srk_sgpr_opaque(a.m_ldc), mkc = srk_sgpr_opaque(a.m_coff);
-  const float alpha = srk_sgpr_opaque(a.alpha), beta1 = srk_sgpr_opaque(a.beta1), beta2 = srk_sgpr_opaque(a.beta2);
-  const float slope = srk_sgpr_opaque(a.slope), mask_slope = srk_sgpr_opaque(a.mask_slope);
+  for (int p = 0; p < 2; ++p) cok[p] = 32 * p + 8 * G + 7 < a.Cout;
+  const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr;
+  const float alpha = a.alpha, beta1 = a.beta1, beta2 = a.beta2, slope = a.slope, mask_slope = a.mask_slope;
   const long img_px = (long)a.OH * a.OW;
   auto rsrc16 = [&](const float* p, int ldc, int coff) {
     const T* q = reinterpret_cast<const T*>(p) + (long)n * img_px * ldc + coff;
@@ -319,22 +325,23 @@ __device__ __forceinline__ void h16_epilogue16(const srk_conv_args& a, f32x4 (&a
   bool sres[NS > 0 ? NS : 1];
   if constexpr (NS >= 1) {
     const bool m0 = !has_r1 && !has_r2;
-    srs[0] = rsrc16(has_r1 ? r1p : (has_r2 ? r2p : mkp), has_r1 ? r1l : (has_r2 ? r2l : mkl), has_r1 ? r1c : (has_r2 ? r2c : mkc));
-    sld[0] = has_r1 ? r1l : (has_r2 ? r2l : mkl);
+    srs[0] = rsrc16(has_r1 ? a.r1 : (has_r2 ? a.r2 : a.mask), has_r1 ? a.r1_ldc : (has_r2 ? a.r2_ldc : a.m_ldc), has_r1 ? a.r1_coff : (has_r2 ? a.r2_coff : a.m_coff));
+    sld[0] = has_r1 ? a.r1_ldc : (has_r2 ? a.r2_ldc : a.m_ldc);
     scoef[0] = has_r1 ? beta1 : (has_r2 ? beta2 : 0.f);
     sms[0] = m0 ? mask_slope : 1.f; sres[0] = !m0;
   }
   if constexpr (NS >= 2) {
     const bool is2 = has_r1 && has_r2;
-    srs[1] = rsrc16(is2 ? r2p : mkp, is2 ? r2l : mkl, is2 ? r2c : mkc);
-    sld[1] = is2 ? r2l : mkl;
+    srs[1] = rsrc16(is2 ? a.r2 : a.mask, is2 ? a.r2_ldc : a.m_ldc, is2 ? a.r2_coff : a.m_coff);
+    sld[1] = is2 ? a.r2_ldc : a.m_ldc;
     scoef[1] = is2 ? beta2 : 0.f;
     sms[1] = is2 ? 1.f : mask_slope; sres[1] = is2;
   }
   if constexpr (NS >= 3) {
-    srs[2] = rsrc16(mkp, mkl, mkc);
-    sld[2] = mkl; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
+    srs[2] = rsrc16(a.mask, a.m_ldc, a.m_coff);
+    sld[2] = a.m_ldc; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
   }
+  H16C_STAMP(0, cstamp, 3);            // (stamped build: set-up of the epilogue done)
 #pragma unroll
   for (int m0 = 0; m0 < MT; m0 += TB) {
     int pix[TB][2];
@@ -371,8 +378,8 @@ __device__ __forceinline__ void h16_epilogue16(const srk_conv_args& a, f32x4 (&a
           float o[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = __builtin_fmaf(acc[m][ph][2 * p][e], alpha, bq[p][e]);
-            o[4 + e] = __builtin_fmaf(acc[m][ph][2 * p + 1][e], alpha, bq[p][4 + e]);
+            o[e] = acc[m][ph][2 * p][e] * alpha;
+            o[4 + e] = acc[m][ph][2 * p + 1][e] * alpha;
           }
 #pragma unroll
           for (int sidx = 0; sidx < NS; ++sidx) {
@@ -396,9 +403,8 @@ __device__ __forceinline__ void h16_epilogue16(const srk_conv_args& a, f32x4 (&a
           }
           if (msigns) {
             const unsigned byte = sbits[it >> 2] >> (8 * (it & 3));
-            const float ms = srk_sgpr_opaque(a.mask_slope);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = ((byte >> e) & 1u) ? o[e] : o[e] * ms;
+            for (int e = 0; e < 8; ++e) o[e] = ((byte >> e) & 1u) ? o[e] : o[e] * mask_slope;
           }
           const bool ok = ((valid >> (2 * mm + ph)) & 1) && cok[p];
           h16_f32x8 ov;
@@ -889,6 +895,9 @@ typedef srk_chain_args h16_chain_args;
 #ifndef CH_NLOAD_N
 #define CH_NLOAD_N 2
 #endif
+#ifndef H16_CHAIN_SKEW_NS
+#define H16_CHAIN_SKEW_NS 0          // default start skew per phase (srk_chain_skew); SRK_H16_CHAIN_SKEW_NS / _GROUPS override
+#endif
 constexpr int CH_NLOAD = CH_NLOAD_N, CH_THREADS = 64 * (4 + CH_NLOAD);      // loader waves of the chain kernel
 // M16 (round 4, the default: H16_CHAIN_M16): the MFMA waves run v_mfma_f32_16x16x32 instead of 32x32x16 -- the same staging, the same LDS
 // image, the same number of fragment reads (72 per stage and wave) and the same MFMA cycles (288 x 16), but
@@ -903,9 +912,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
   typedef typename H16<T>::v8 v8;
   constexpr int MT = 4;
   typedef HGeo<MT> G;
-  __shared__ float4 smem[2 * G::STAGE4 + 1];
+  __shared__ float4 smem[2 * G::STAGE4 + 1 + 16];
   unsigned* const wg_cnt = reinterpret_cast<unsigned*>(smem + 2 * G::STAGE4);
   volatile unsigned* const wg_go = wg_cnt + 1;           // the census verdict (srk_chain.h): 1 = every workgroup is resident, 2 = give up
+  float* const lds_bias = reinterpret_cast<float*>(smem + 2 * G::STAGE4 + 1);      // (M16) the 64 biases of the conv about to start
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -924,6 +934,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
   const int oh0 = ty * G::TH, ow0 = tx * HW_TW;
   const int nconv = A.n;
   if (tid == 0) *wg_cnt = 0;
+  srk_chain_skew(A);
 
   if (wv >= 4) {
     // ------------------------------------------------------------------------------------------------------ loader waves
@@ -931,7 +942,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     constexpr int NXJ = (G::HPIECES + CH_NLOAD - 1) / CH_NLOAD, NWJ = G::WPIECES / CH_NLOAD;
     const unsigned wvo = (unsigned)(lane * 16);
     // census, step 1: loader wave 0 counts the workgroup in before anything else (its verdict is due before conv 0's epilogue)
-    bool census_in = true;
+    int census_in = 1;
     if (lw == 0 && lane == 0) census_in = srk_chain_census_arrive(A);
     const srk_chain_watch watch = srk_chain_watch_of(A.flags, lane, n, ty, tx, tilesH, tilesW);     // lanes 0..8: the eight neighbouring tiles
     auto wait_flags = [&](unsigned target) { srk_chain_wait(watch, target, A.err, lane); };
@@ -977,11 +988,30 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
         h16_dma(wrs, dst + G::WBASE + w * 64, wvo, (unsigned)((q * 36 + w) * CoutP * 16));
       }
     };
+    // (M16) the bias of the conv about to start goes through the LDS into the accumulators' initial values: loader wave 0 fetches it in
+    // front of the stage that is issued beside it and writes it behind that stage's own vmcnt(0) -- visible behind the barrier that follows
+    float bias_v = 0.f;
+    bool bias_pending = false;
+    auto bias_fetch = [&](const srk_conv_args& a) {
+      if (M16 && lw == 0) {
+        bias_v = (a.bias && lane < a.Cout) ? a.bias[lane] : 0.f;
+        bias_pending = true;
+      }
+    };
+    auto bias_put = [&]() {
+      if (M16 && bias_pending) {
+        lds_bias[lane] = bias_v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bias_pending = false;
+      }
+    };
     setup(A.c[0]);
+    bias_fetch(A.c[0]);
     stage(0, 0, false);
     for (int c = 0; c < nconv; ++c) {
       const int nq = A.c[c].Cin >> 5;                     // even, >= 4 behind the first conv (host-checked)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bias_put();
       __builtin_amdgcn_s_barrier();                       // this conv's stage 0 is in LDS; the epilogue scratch (buffer 1) is free
       for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) {
@@ -992,7 +1022,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
             // census, step 2, beside the first stage's MFMAs and with stage 1 in flight: wait (bounded) until the whole grid is resident.
             // The verdict goes through the LDS; every wave reads it behind the last stage barrier of conv 0 (>= one barrier from here),
             // i.e. before the first store and before the first flag wait of the launch.
-            if (lane == 0) { *wg_go = (census_in && srk_chain_census_wait(A)) ? 1u : 2u; }
+            if (lane == 0) { *wg_go = srk_chain_census_wait(A, census_in) ? 1u : 2u; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
           if (c > 0 && q == 0 && lw == 0) {
@@ -1005,9 +1035,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
           }
         } else if (c + 1 < nconv) {
           setup(A.c[c + 1]);                              // the next conv's first stage (old slices) beside this conv's last one
+          bias_fetch(A.c[c + 1]);
           stage(0, 0, H16_CHAIN_ALL_DEV != 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bias_put();           // (the next conv's bias: the MFMA waves read it behind THIS barrier, in front of their accumulators' reset)
         __builtin_amdgcn_s_barrier();
       }
       if (c == 0 && *wg_go != 1u) return;              // census failed: all six waves leave here (the MFMA waves in front of their epilogue)
@@ -1127,22 +1159,32 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
       __builtin_amdgcn_s_barrier();
       [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (step(std::integral_constant<int, STEPS - DEFER + Ls>{}), ...); }(std::make_integer_sequence<int, DEFER>{});
     };
-    for (int c = 0; c < nconv; ++c) {
-      const srk_conv_args& a = A.c[c];
-      const int nq = a.Cin >> 5;
-      frag_addresses();
+    // the accumulators start at the bias (lds_bias: written by loader wave 0 one barrier earlier): lane (n16, Gl) owns channels 32 p + 8 Gl + 4 j + reg
+    auto acc_init = [&]() {
+      int lo = lane;
+      asm volatile("" : "+v"(lo));
+      const f32x4* bl = reinterpret_cast<const f32x4*>(lds_bias + 8 * (lo >> 4));
+      f32x4 bv[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) bv[f] = bl[8 * (f >> 1) + (f & 1)];          // 32 p + 4 j floats on
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][ph][f][r] = 0.f;
+          for (int f = 0; f < 4; ++f) acc[m][ph][f] = bv[f];
+    };
+    for (int c = 0; c < nconv; ++c) {
+      const srk_conv_args& a = A.c[c];
+      const int nq = a.Cin >> 5;
+      const h16_epi_pre ep = h16_epi_fetch(a);
+      frag_addresses();
+      if (c > 0) acc_init();           // (conv 0: its bias becomes visible behind the barrier below)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       H16C_STAMP(0, c, 0);
+      if (c == 0) acc_init();
       head(I0{});
       for (int q = 0; q < nq; q += 2) {
         stage_fn(I0{});
@@ -1151,11 +1193,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       H16C_STAMP(0, c, 1);
       if (c == 0 && *wg_go != 1u) return;                // census (srk_chain.h): the grid is not resident -- nothing has been stored
-      const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
-      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(a, acc, n, oh0, ow0, wv, lane, tile);
-      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(a, acc, n, oh0, ow0, wv, lane, tile);
-      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(a, acc, n, oh0, ow0, wv, lane, tile);
-      else h16_epilogue16<T, MT, 3, STORE_AUX>(a, acc, n, oh0, ow0, wv, lane, tile);
+      const int n_aux = (ep.r1 ? 1 : 0) + (ep.r2 ? 1 : 0) + (ep.mask ? 1 : 0);
+      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
+      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
+      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
+      else h16_epilogue16<T, MT, 3, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
       H16C_STAMP(0, c, 2);
       sig_pending = c + 1 < nconv;
     }
@@ -1482,6 +1524,9 @@ int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) 
   const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
   if (rc != 1) return rc;
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
+  static unsigned sk_ns = ~0u, sk_g = 0;          // (the environment is read once)
+  if (sk_ns == ~0u) { srk_chain_skew_of("H16", H16_CHAIN_SKEW_NS, 4, &A); sk_ns = A.skew_ticks; sk_g = A.skew_groups; }
+  A.skew_ticks = sk_ns; A.skew_groups = sk_g;
   if (h16_chain_m16()) {
     if (f.wp_format == 7) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, true>), grid, dim3(CH_THREADS), 0, st, A);
     else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, true>), grid, dim3(CH_THREADS), 0, st, A);

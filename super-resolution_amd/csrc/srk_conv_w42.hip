@@ -32,6 +32,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef W42_CH_PREFETCH1
 #define W42_CH_PREFETCH1 0       // 1: chain form of the 16-row kernel: prefetch across the link boundary (PF in wino42_body).  It has the registers
 #endif                           // (no spill), so this is what the 32-row kernel could gain: block 276.0 -> 273.9 / 284.8 -> 277.7 us, step 60.9 -> 61.5 ms
+#ifndef W42_CENSUS
+#define W42_CENSUS 1             // timing-only switch: 0 = the chain kernels without their census (srk_chain.h), 2 = count in but do not wait
+#endif
+#ifndef W42_CHAIN_SKEW_NS
+#define W42_CHAIN_SKEW_NS 0      // default start skew per phase of the chain kernels (srk_chain.h: srk_chain_skew); SRK_W42_CHAIN_SKEW_NS / _GROUPS override
+#endif
 #ifndef W42_CHAIN_SIGNS
 #define W42_CHAIN_SIGNS 0        // 1: sign bits (srk_conv_args.signs) in the chain kernels.  Correct (bit-identical to the mask tensors), but with
 #endif                           // them compiled in the 32-row chain kernel spills 131 registers around its exchange / epilogue: 455 -> 490 us per block
@@ -100,8 +106,8 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
   // K loop (below), by which time -- the halo address arithmetic and the first chunk's flight lie in between -- every workgroup of a
   // resident grid has long arrived, so the wait costs one load that returns beside the first chunk.
   __shared__ unsigned census_go;
-  bool census_in = true;
-  if constexpr (CHAIN) { if (c == 0 && tid == 0) census_in = srk_chain_census_arrive(*A); }
+  int census_in = 1;
+  if constexpr (CHAIN && W42_CENSUS != 0) { if (c == 0 && tid == 0) census_in = srk_chain_census_arrive(*A); }
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // = row position p of this wave
   const int hl = lane >> 5, l32 = lane & 31;
   const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
@@ -387,8 +393,8 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
     if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
   }
   W42_STAMP(1);
-  if constexpr (CHAIN) {
-    if (c == 0 && tid == 0) census_go = (census_in && srk_chain_census_wait(*A)) ? 1u : 2u;      // (visible behind the barrier below)
+  if constexpr (CHAIN && W42_CENSUS == 1) {
+    if (c == 0 && tid == 0) census_go = srk_chain_census_wait(*A, census_in) ? 1u : 2u;      // (visible behind the barrier below)
   }
   __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
 #pragma unroll
@@ -407,7 +413,7 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if constexpr (CHAIN) {
+  if constexpr (CHAIN && W42_CENSUS == 1) {
     // the grid is not resident (census): leave before anything is stored or waited for; every workgroup of the launch takes this exit
     if (c == 0 && *reinterpret_cast<volatile unsigned*>(&census_go) != 1u) return false;
   }
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_wino42_kernel(const srk_conv_
 template <int NMT>
 __global__ __launch_bounds__(256) void conv3x3_f32_wino42_chain_kernel(const srk_chain_args A) {
   f32x2 P0[6][2];          // (16-row form: the next conv's first weights, fetched by the previous link)
+  srk_chain_skew(A);
   for (int c = 0; c < A.n; ++c) {
     if (!wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0)) return;
   }
@@ -640,6 +647,9 @@ int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st) 
   const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
   if (rc != 1) return rc;
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
+  static unsigned sk_ns = ~0u, sk_g = 0;
+  if (sk_ns == ~0u) { srk_chain_skew_of("W42", W42_CHAIN_SKEW_NS, 4, &A); sk_ns = A.skew_ticks; sk_g = A.skew_groups; }
+  A.skew_ticks = sk_ns; A.skew_groups = sk_g;
   if (nmt == 2) hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<2>, grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<1>, grid, dim3(256), 0, st, A);
   const bool ok = hipGetLastError() == hipSuccess;

@@ -33,6 +33,7 @@ def _reset_form(U):
     yield
     U.L.lib().srk_debug_set_h16_mt(0)
     U.L.lib().srk_debug_set_h16_chain(1)
+    U.L.lib().srk_debug_set_h16_chain_m16(1)
 
 
 def _q(t, fmt):
@@ -394,42 +395,64 @@ def test_h16_chain_matches_separate_launches(U, fmt, backward, n, h, w):
             assert torch.equal(D, first[0]) and torch.equal(out, first[1])
 
 
-def test_h16_chain_writes_and_reads_the_same_sign_bits_as_separate_launches(U):
-    """forward sequence with sign bits through the chain form and conv by conv: same bits; data-gradient sequence masked by them: the
-    chain's results within the usual last place of the separate launches'"""
+@pytest.mark.parametrize("m16", [1, 0])
+def test_h16_chain_writes_and_reads_the_same_sign_bits_as_separate_launches(U, m16):
+    """Forward sequence with sign bits through the chain form and conv by conv, then the data-gradient sequence masked by them.
+    m16 = 0 (the 32x32x16 form of the chain kernel): the SAME bit layout as the one-conv kernels -- equal buffers, and either path may read
+    the other's bits.  m16 = 1 (the default 16x16x32 form): a layout of its own, told apart by srk_conv3x3_seq_signs_tag -- each path reads
+    the bits IT wrote, and the two data-gradient results agree within the usual last place."""
     L = U.L
-    n, h, w = 8, 128, 128
-    D, out, calls, keep = _dense_block_calls(U, 7, n, h, w, False, 600)
-    nb = L.conv_signs_bytes(calls[0][0], calls[0][1], calls[0][2], calls[0][3], **calls[0][4])
-    sg = [torch.zeros(4, nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    for mode, s_ in ((0, sg[0]), (1, sg[1])):
-        L.lib().srk_debug_set_h16_chain(mode)
-        D[..., 64:] = 0
-        cs = [(x, wp, b, y, dict(kw, signs_out=s_[k]) if k < 4 else kw) for k, (x, wp, b, y, kw) in enumerate(calls)]
-        assert (_seq_kernel(L, cs) != "") == (mode == 1)
-        L.conv3x3_seq(cs)
-        torch.cuda.synchronize()
-    # the two forward paths differ in the last place of a few outputs (order of the fp32 sums): so may a few sign bits of values next to zero
-    diff = (sg[0] != sg[1]).float().mean().item()
-    assert diff < 1e-3
-    Db, outb, callsb, keepb = _dense_block_calls(U, 7, n, h, w, True, 601)
-    res = []
-    for mode in (0, 1):
-        L.lib().srk_debug_set_h16_chain(mode)
-        Db[..., 64:] = 0
-        outb.zero_()
-        cs = []
-        for k, (x, wp, b, y, kw) in enumerate(callsb):
-            kw = dict(kw)
-            if k < 4:
-                kw.pop("mask")
-                kw["mask_signs"] = sg[1][k]
-            cs.append((x, wp, b, y, kw))
-        L.conv3x3_seq(cs)
-        torch.cuda.synchronize()
-        res.append((Db.float().clone(), outb.float().clone()))
-    tol = 6 * TOL16[7] * res[0][0].abs().max().item()
-    assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol
+    L.lib().srk_debug_set_h16_chain_m16(m16)
+    try:
+        n, h, w = 8, 128, 128
+        D, out, calls, keep = _dense_block_calls(U, 7, n, h, w, False, 600)
+        nb = L.conv_signs_bytes(calls[0][0], calls[0][1], calls[0][2], calls[0][3], **calls[0][4])
+        sg = [torch.zeros(4, nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        tags = []
+        for mode, s_ in ((0, sg[0]), (1, sg[1])):
+            L.lib().srk_debug_set_h16_chain(mode)
+            D[..., 64:] = 0
+            cs = [(x, wp, b, y, dict(kw, signs_out=s_[k]) if k < 4 else kw) for k, (x, wp, b, y, kw) in enumerate(calls)]
+            assert (_seq_kernel(L, cs) != "") == (mode == 1)
+            nbs, tag = L.conv_seq_signs(cs)
+            assert nbs == nb and tag != 0
+            tags.append(tag)
+            L.conv3x3_seq(cs)
+            torch.cuda.synchronize()
+        assert (tags[0] == tags[1]) == (m16 == 0)
+        if m16 == 0:
+            # the two forward paths differ in the last place of a few outputs (order of the fp32 sums): so may a few sign bits next to zero
+            assert (sg[0] != sg[1]).float().mean().item() < 1e-3
+        else:
+            # same number of positive outputs (up to those few), different places
+            np = __import__("numpy")
+            pop = [int(np.unpackbits(t.cpu().numpy()).sum()) for t in sg]
+            assert abs(pop[0] - pop[1]) < 1e-3 * pop[0] and pop[1] == int((D[..., 64:].float() > 0).sum().item())
+        Db, outb, callsb, keepb = _dense_block_calls(U, 7, n, h, w, True, 601)
+        res = []
+        for mode in (0, 1):
+            L.lib().srk_debug_set_h16_chain(mode)
+            Db[..., 64:] = 0
+            outb.zero_()
+            cs = []
+            for k, (x, wp, b, y, kw) in enumerate(callsb):
+                kw = dict(kw)
+                if k < 4:
+                    kw.pop("mask")
+                    kw["mask_signs"] = sg[1 if m16 == 0 else mode][k]       # (m16: every path reads the bits its own form wrote)
+                cs.append((x, wp, b, y, kw))
+            L.conv3x3_seq(cs)
+            torch.cuda.synchronize()
+            res.append((Db.float().clone(), outb.float().clone()))
+        # (m16: the two mask sets come from two forward runs that differ in the last place of a few outputs: a few masks next to zero differ)
+        tol = 6 * TOL16[7] * res[0][0].abs().max().item()
+        if m16 == 0:
+            assert (res[0][0] - res[1][0]).abs().max().item() <= tol and (res[0][1] - res[1][1]).abs().max().item() <= tol
+        else:
+            bad = ((res[0][0] - res[1][0]).abs() > tol).float().mean().item()
+            assert bad < 1e-3, bad
+    finally:
+        L.lib().srk_debug_set_h16_chain_m16(1)
 
 
 def test_h16_chain_eligibility(U):
@@ -438,7 +461,7 @@ def test_h16_chain_eligibility(U):
     L = U.L
     L.lib().srk_debug_set_h16_chain(2)
     D, out, calls, keep = _dense_block_calls(U, 7, 1, 16, 32, False, 400)
-    assert _seq_kernel(L, calls).startswith("conv3x3_h16_chain_kernel<_Float16>")
+    assert _seq_kernel(L, calls).startswith("conv3x3_h16_chain_kernel<_Float16, ")
     assert _seq_kernel(L, calls[:1]) == ""                                     # a single conv
     assert _seq_kernel(L, calls[1:3]).startswith("conv3x3_h16_chain_kernel")   # any sub-sequence of the pattern
     # conv 3 reading, as an OLD slice, what conv 2 has just written: not the pattern (swap the order of two convs)
@@ -582,7 +605,7 @@ def test_h16_configs4_batch8_launch_set_vs_oracle(srk, mode):
     finally:
         ran = L.KernelTimer.stop()
     # ---- what ran: 3 R forward + 3 R data-gradient chain launches, 3 R loader-form batched weight gradients
-    chain = f"conv3x3_h16_chain_kernel<{tname}>"
+    chain = f"conv3x3_h16_chain_kernel<{tname}, true>"
     loader = f"wgrad_h16_kernel<{tname}, 0, true, 8>+reduce"
     assert chain in ran and ran[chain]["n"] == 6 * R, sorted(ran)
     assert loader in ran and ran[loader]["n"] >= 3 * R, sorted(ran)

@@ -93,7 +93,7 @@ if __name__ == "__main__":
     for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (TN, THW, THW)):
         for bw in (False, True):
             r = check(N, H, W, reps if N < 8 else 3 * reps, bw)
-            bad += r > (0.0 if fmt == 6 else 4e-3)
+            bad += r > {6: 0.0, 7: 4e-3, 8: 3.2e-2}[fmt]          # (16-bit: a few units in the last place of the storage type: 2^-10 / 2^-7)
     print("MISMATCH" if bad else "results agree", flush=True)
     if not bad and not os.environ.get("NO_TIMING"):
         timing(TN, THW, THW, False)

@@ -27,6 +27,8 @@ print("conv | start (min med max) | main loop done (med) | epilogue issued (med)
 for c in range(5):
     st, ml, ep = s[:, c, 0] - t0, s[:, c, 1] - t0, s[:, c, 2] - t0
     line = "%d    | %6.2f %6.2f %6.2f | %6.2f | %6.2f | %5.2f | %5.2f |" % (c, st.min(), st.median(), st.max(), ml.median(), ep.median(), (ml - st).median(), (ep - ml).median())
+    if s[:, c, 3].max() > 0:          # (16x16x32 form: the epilogue's set-up -- argument loads, bias -- ends here)
+        line += " setup %4.2f |" % (s[:, c, 3] - t0 - ml).median()
     if c > 0:
         w0, w1 = s[:, c, 4] - t0, s[:, c, 5] - t0
         line += " %6.2f | %5.2f %5.2f | %6.2f" % (w0.median(), (w1 - w0).median(), (w1 - w0).max(), (s[:, c, 6] - t0).median())
