@@ -223,6 +223,7 @@ def main():
     L = sr._lib
 
     dist = None
+    comm_info = None               # (N > 1: backend / world size as the communicator reports them, in the JSON line as "comm")
     force_dist = os.environ.get("SRK_FORCE_DIST", "0") == "1"      # rehearse the N>1 code path with a 1-rank RCCL group
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -241,6 +242,10 @@ def main():
             warm = torch.ones(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            # what the communicator itself says: after a SUM of ones every rank holds the number of ranks that took part
+            comm_info = {"backend": dist.get_backend() + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(),
+                         "ranks_counted_by_all_reduce": int(warm.item()),
+                         "devices_visible": torch.cuda.device_count(), "rank0_device": torch.cuda.get_device_name(dev)}
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -437,6 +442,8 @@ def main():
         }
         if subs is not None:
             out["configs"] = subs
+        if comm_info is not None:
+            out["comm"] = comm_info
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

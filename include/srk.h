@@ -35,7 +35,7 @@ typedef enum srk_status {
   SRK_ERR_ALIGNMENT = -3,      /* view not 16-byte aligned where a vector path needs */
   SRK_ERR_WORKSPACE = -4,      /* workspace too small                                */
   SRK_ERR_LAUNCH = -5,         /* hipLaunchKernel reported an error                 */
-  SRK_ERR_CHAIN_TIMEOUT = -6   /* a chain launch (srk_conv3x3_seq) gave up: not resident within its bound, or a flag wait timed out.
+  SRK_ERR_CHAIN_TIMEOUT = -6   /* a chain launch (srk_conv3x3_seq) gave up: a neighbouring tile did not publish within the bound.
                                   Nothing was launched by THIS call; call srk_chain_recover(), then repeat the iteration */
 } srk_status;
 
@@ -128,11 +128,11 @@ int srk_conv3x3_seq(const srk_conv_args* args, int n, void* stream);
  * end.  Results: wp_format 6 bit-identical to the separate launches; 7 / 8 identical up to the order of the fp32 sums (one unit in the
  * last place of the 16-bit outputs).  At most one chain kernel is in flight per device (launches on different streams are ordered by
  * an event).
- * SINGLE TENANT: a chain kernel needs all of its workgroups resident at once, i.e. the process has the GPU to itself (one process per
- * GPU).  Every launch starts with a CENSUS: each workgroup counts itself in and waits -- at most SRK_CHAIN_ENTRY_MS, default 50 ms --
- * until the whole grid has; if it has not (another process on the GPU, a kernel of another stream holding CUs for that long), every
- * workgroup returns before anything is stored and before unpublished data is consumed.  A flag wait inside a launch is bounded too
- * (30 s; behind a passed census it only trips on a fault).  Either way a host-visible fault word is set, and from then on
+ * SINGLE TENANT: a chain kernel's tiles wait for their neighbours, which must therefore be resident: the process has the GPU to itself
+ * (one process per GPU).  Every wait is bounded: SRK_CHAIN_WAIT_MS, default 50 ms (nothing of this process holds a CU that long).  A tile
+ * whose neighbour has not published in time (another process on the GPU, a kernel of another stream holding CUs for that long) raises a
+ * host-visible fault word, poisons a device word and drains -- no further waiting, neither in this tile nor, once they see the poison,
+ * in any other: the launch ends in its usual time; what it writes is garbage in activation buffers.  From then on
  *   - srk_adam_count_step tells the optimizer step that follows to skip itself, ON THE DEVICE (no weight ever sees a gradient computed
  *     from a launch that gave up, however far the host has run ahead),
  *   - the next srk_conv3x3_seq / srk_adam_* call returns SRK_ERR_CHAIN_TIMEOUT and launches nothing,
@@ -147,17 +147,17 @@ int srk_debug_set_w42_chain(int mode);
 /* MFMA shape of the 16-bit chain kernel: 1 (default; SRK_H16_CHAIN_M16) = v_mfma_f32_16x16x32 with the weights as the row operand and an
  * epilogue that stores straight from the accumulators; 0 = the 32x32x16 form (A/B measurements, tests) */
 int srk_debug_set_h16_chain_m16(int on);
-/* pending fault code (1: census, 2: flag wait; 0: none) after waiting for the device, cleared; < 0: error.  See above. */
+/* pending fault code (0: none) after waiting for the device, cleared; < 0: error.  See above. */
 int srk_chain_recover(void);
 /* chain launches so far / wrap resets of the flag epoch / recovered time-outs / sequence calls left in the back-off (any may be NULL) */
 int srk_chain_stats(unsigned long long* launches, unsigned long long* resets, int* strikes, long* off_calls);
-/* The flag epoch and the census count are 32-bit and compared as differences; before either would pass 2^30 the library zeroes them and the
- * flag array on the launching stream.  This is that decision as pure arithmetic (CPU-testable): given the current values and the next
- * launch (n convs, `tiles` workgroups) it returns the values the launch uses and whether the reset precedes it. */
-int srk_chain_epoch_plan(unsigned epoch, unsigned arrive_base, int n, int tiles, unsigned* epoch_out, unsigned* arrive_out, int* reset);
-/* bound of the census wait in microseconds (0: back to SRK_CHAIN_ENTRY_MS / 50 ms).  A data-parallel job sets it to seconds: a
- * collective's kernel holds CUs while a peer rank is late, and a chain launch behind it has to wait that out. */
-int srk_chain_set_entry_us(unsigned us);
+/* The flag epoch is 32-bit and flags are compared as differences; before it would pass 2^30 the library zeroes it and the flag array on
+ * the launching stream.  This is that decision as pure arithmetic (CPU-testable): given the current epoch and the next launch (n convs)
+ * it returns the epoch the launch uses and whether the reset precedes it. */
+int srk_chain_epoch_plan(unsigned epoch, int n, unsigned* epoch_out, int* reset);
+/* bound of every wait of a chain launch in microseconds (0: back to SRK_CHAIN_WAIT_MS / 50 ms).  A data-parallel job sets it to seconds:
+ * a collective's kernel holds CUs while a peer rank is late, and a tile behind it has to wait that out. */
+int srk_chain_set_wait_us(unsigned us);
 /* test aids: set the epoch (to cross the wrap in a test) and the back-off; pretend a launch timed out; occupy `workgroups` CUs for `usec`
  * microseconds on `stream` (one 4-wave workgroup with 64 KB of LDS each: no chain workgroup fits beside it) -- the stand-in for a
  * collective's kernel in tools/debug/holder_bench.py */

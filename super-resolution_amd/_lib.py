@@ -22,7 +22,7 @@ EXPORTS = [
     "srk_loss_workspace_bytes", "srk_sigmoid_fwd", "srk_sigmoid_bwd", "srk_lrelu_grad_mul", "srk_soft_count_fwd", "srk_soft_count_bwd",
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_jet_extract", "srk_strerror", "srk_version",
-    "srk_chain_recover", "srk_chain_stats", "srk_chain_epoch_plan", "srk_debug_chain_set", "srk_chain_set_entry_us", "srk_debug_chain_inject_fault",
+    "srk_chain_recover", "srk_chain_stats", "srk_chain_epoch_plan", "srk_debug_chain_set", "srk_chain_set_wait_us", "srk_debug_chain_inject_fault",
     "srk_debug_hold_cus", "srk_adam_count_step", "srk_debug_chain_inject_fault_async",
 ]
 ERR_CHAIN_TIMEOUT = -6
@@ -162,9 +162,9 @@ def lib():
         L.srk_conv3x3_seq_signs_tag.argtypes = [C.POINTER(ConvArgs), C.c_int]
         L.srk_chain_recover.argtypes = []
         L.srk_chain_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_long)]
-        L.srk_chain_epoch_plan.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+        L.srk_chain_epoch_plan.argtypes = [C.c_uint, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
         L.srk_debug_chain_set.argtypes = [C.c_uint, C.c_long]
-        L.srk_chain_set_entry_us.argtypes = [C.c_uint]
+        L.srk_chain_set_wait_us.argtypes = [C.c_uint]
         L.srk_debug_chain_inject_fault.argtypes = [C.c_uint]
         L.srk_debug_chain_inject_fault_async.argtypes = [_fp]
         L.srk_debug_hold_cus.argtypes = [C.c_int, C.c_int, _fp]
@@ -180,9 +180,9 @@ def lib():
 
 
 class ChainTimeout(RuntimeError):
-    """SRK_ERR_CHAIN_TIMEOUT: a chain launch (one persistent kernel per dense-block sequence) gave up -- its grid was not resident within
-    the census bound, or a flag wait timed out.  The call that raised launched nothing; optimizer steps skip themselves on the device
-    while the fault is pending.  chain_recover(), then repeat the iteration (train.Stepper.step does both)."""
+    """SRK_ERR_CHAIN_TIMEOUT: a chain launch (one persistent kernel per dense-block sequence) gave up -- a tile's neighbour did not
+    publish within the wait bound (it was not resident).  The call that raised launched nothing; optimizer steps skip themselves on the
+    device while the fault is pending.  chain_recover(), then repeat the iteration (train.Stepper.step does both)."""
 
 
 def check(status: int, what: str):

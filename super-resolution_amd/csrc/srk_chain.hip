@@ -6,13 +6,12 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int CHAIN_WORDS = SRK_CHAIN_FLAGS + 32;        // flags + the census count + its "go" word (64 bytes each), one uncached block
+constexpr int CHAIN_WORDS = SRK_CHAIN_FLAGS + 16;        // flags + the poison word (its own 64 bytes), one uncached block
 struct ChainDev {
-  unsigned* flags = nullptr;   // one word per tile (device), then the census word at [SRK_CHAIN_FLAGS]
-  unsigned* err = nullptr;     // pinned host word a kernel writes when a wait ran into its time limit (1: census, 2: flag wait)
+  unsigned* flags = nullptr;   // one word per tile (device), then the poison word at [SRK_CHAIN_FLAGS]
+  unsigned* err = nullptr;     // pinned host word a kernel writes when a wait ran into its bound
   unsigned epoch = 0;
-  unsigned arrive_base = 0;    // value of the census count when the next launch starts (if nothing has been poisoned)
-  unsigned entry_ticks = 5000000;
+  unsigned wait_ticks = 5000000;   // bound of every wait of a launch (100 MHz ticks): SRK_CHAIN_WAIT_MS, srk_chain_set_wait_us
   int cus = 0;
   hipEvent_t ev = nullptr;     // end of the newest chain launch, once a second stream has shown up
   hipStream_t last = nullptr;
@@ -23,6 +22,14 @@ struct ChainDev {
 };
 ChainDev g_dev[16];
 std::mutex g_mu;
+
+unsigned wait_ticks_from_env() {
+  const char* e = getenv("SRK_CHAIN_WAIT_MS");          // bound of every wait of a chain launch
+  double ms = e ? atof(e) : 50.0;
+  if (!(ms >= 0.01)) ms = 0.01;
+  if (ms > 40000.0) ms = 40000.0;
+  return (unsigned)(ms * 100000.0);
+}
 
 ChainDev* chain_dev() {
   int dev = 0;
@@ -44,24 +51,19 @@ ChainDev* chain_dev() {
       return nullptr;
     }
     *D.err = 0;
-    const char* e = getenv("SRK_CHAIN_ENTRY_MS");          // bound of the census wait
-    double ms = e ? atof(e) : 50.0;
-    if (!(ms >= 0.01)) ms = 0.01;
-    if (ms > 30000.0) ms = 30000.0;
-    D.entry_ticks = (unsigned)(ms * 100000.0);
+    D.wait_ticks = wait_ticks_from_env();
   }
   return D.dead ? nullptr : &D;
 }
 }  // namespace
 
-// What the host does to epoch / census count before a launch of n convs on `tiles` workgroups: *reset = 1 if both (and the flag array)
-// must be zeroed first, so that neither passes SRK_CHAIN_WRAP.  Pure arithmetic (CPU-tested: tests/test_host_cpu.py); flags compare as
-// (int)(flag - target) >= 0, which is only right while |flag - target| < 2^31: with every live value below 2^30 + 8 it always is.
-extern "C" int srk_chain_epoch_plan(unsigned epoch, unsigned arrive_base, int n, int tiles, unsigned* epoch_out, unsigned* arrive_out, int* reset) {
-  if (n <= 0 || n > SRK_CHAIN_MAX || tiles <= 0 || tiles > SRK_CHAIN_FLAGS || !epoch_out || !arrive_out || !reset) return SRK_ERR_BAD_ARG;
-  *reset = (epoch >= SRK_CHAIN_WRAP - (unsigned)n || arrive_base >= SRK_CHAIN_WRAP - (unsigned)tiles) ? 1 : 0;
-  if (*reset) { epoch = 0; arrive_base = 0; }
-  *epoch_out = epoch; *arrive_out = arrive_base;
+// What the host does to the epoch before a launch of n convs: *reset = 1 if it (and the flag array) must be zeroed first, so that it never
+// passes SRK_CHAIN_WRAP.  Pure arithmetic (CPU-tested: tests/test_host_cpu.py); flags compare as (int)(flag - target) >= 0, which is only
+// right while |flag - target| < 2^31: with every live value below 2^30 + 8 it always is.
+extern "C" int srk_chain_epoch_plan(unsigned epoch, int n, unsigned* epoch_out, int* reset) {
+  if (n <= 0 || n > SRK_CHAIN_MAX || !epoch_out || !reset) return SRK_ERR_BAD_ARG;
+  *reset = epoch >= SRK_CHAIN_WRAP - (unsigned)n ? 1 : 0;
+  *epoch_out = *reset ? 0u : epoch;
   return SRK_OK;
 }
 
@@ -109,11 +111,9 @@ int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A) {
     // an earlier chain launch timed out.  Nothing more is launched as a chain until the caller has recovered (srk_chain_recover); the
     // word stays set, so that every srk_adam_step already queued or still to come skips its update.
     if (!D->fault_reported) {
-      fprintf(stderr, code == 1 ? "libsrk: a conv3x3 chain launch gave up at its census: not every workgroup became resident within the bound "
-                                  "(SRK_CHAIN_ENTRY_MS; another process or a long kernel holding CUs?).  It stored nothing; optimizer steps are skipped "
-                                  "until srk_chain_recover()\n"
-                                : "libsrk: a conv3x3 chain launch timed out waiting for a neighbouring tile (its results are invalid); optimizer steps are "
-                                  "skipped until srk_chain_recover()\n");
+      (void)code;
+      fprintf(stderr, "libsrk: a conv3x3 chain launch gave up: a neighbouring tile did not publish within the bound (SRK_CHAIN_WAIT_MS; another "
+                      "process or a long kernel holding CUs?).  Its results are invalid; optimizer steps are skipped until srk_chain_recover()\n");
       D->fault_reported = true;
     }
     g_mu.unlock();
@@ -139,16 +139,16 @@ int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A) {
     } else if (hipStreamWaitEvent(st, D->ev, 0) != hipSuccess) { g_mu.unlock(); return SRK_ERR_LAUNCH; }
   }
   int reset = 0;
-  srk_chain_epoch_plan(D->epoch, D->arrive_base, n, tiles, &D->epoch, &D->arrive_base, &reset);
+  srk_chain_epoch_plan(D->epoch, n, &D->epoch, &reset);
   if (reset) {
     if (hipMemsetAsync(D->flags, 0, CHAIN_WORDS * sizeof(unsigned), st) != hipSuccess) { g_mu.unlock(); return SRK_ERR_LAUNCH; }
     ++D->resets;
   }
+  (void)tiles;
   A->n = n; A->epoch = D->epoch; A->flags = D->flags; A->err = D->err;
-  A->arrive = D->flags + SRK_CHAIN_FLAGS; A->arrive_target = D->arrive_base + (unsigned)tiles; A->entry_ticks = D->entry_ticks;
+  A->poison = D->flags + SRK_CHAIN_FLAGS; A->wait_ticks = D->wait_ticks;
   A->skew_ticks = 0; A->skew_groups = 1;
   D->epoch += (unsigned)n;
-  D->arrive_base += (unsigned)tiles;
   return 1;
 }
 
@@ -187,7 +187,7 @@ extern "C" int srk_chain_recover(void) {
   const unsigned code = *reinterpret_cast<volatile unsigned*>(D->err);
   if (hipMemset(D->flags, 0, CHAIN_WORDS * sizeof(unsigned)) != hipSuccess) return SRK_ERR_LAUNCH;
   *D->err = 0;
-  D->epoch = 0; D->arrive_base = 0; D->fault_reported = false;
+  D->epoch = 0; D->fault_reported = false;
   if (code) {
     const int k = D->strikes < 5 ? D->strikes : 5;
     D->off_calls = 64L << (3 * k);
@@ -236,22 +236,16 @@ extern "C" int srk_debug_chain_set(unsigned epoch, long off_calls) {
   if (hipDeviceSynchronize() != hipSuccess) return SRK_ERR_LAUNCH;
   // (flags older than the new epoch: whatever they hold compares as "not yet" or is overwritten; zero them to keep the invariant simple)
   if (hipMemset(D->flags, 0, CHAIN_WORDS * sizeof(unsigned)) != hipSuccess) return SRK_ERR_LAUNCH;
-  D->epoch = epoch; D->arrive_base = 0; D->off_calls = off_calls;
+  D->epoch = epoch; D->off_calls = off_calls;
   if (off_calls == 0) D->strikes = 0;
   return SRK_OK;
 }
-// bound of the census wait in microseconds (0: back to SRK_CHAIN_ENTRY_MS / 50 ms); srk.h
-extern "C" int srk_chain_set_entry_us(unsigned us) {
+// bound of every wait of a chain launch in microseconds (0: back to SRK_CHAIN_WAIT_MS / 50 ms); srk.h
+extern "C" int srk_chain_set_wait_us(unsigned us) {
   std::lock_guard<std::mutex> lk(g_mu);
   ChainDev* D = chain_dev();
   if (!D) return SRK_ERR_UNSUPPORTED;
-  if (us == 0) {
-    const char* e = getenv("SRK_CHAIN_ENTRY_MS");
-    double ms = e ? atof(e) : 50.0;
-    if (!(ms >= 0.01)) ms = 0.01;
-    if (ms > 30000.0) ms = 30000.0;
-    D->entry_ticks = (unsigned)(ms * 100000.0);
-  } else D->entry_ticks = us * 100u;
+  D->wait_ticks = us == 0 ? wait_ticks_from_env() : (us > 40000000u ? 4000000000u : us * 100u);
   return SRK_OK;
 }
 // the same from the DEVICE side of `stream` (a memset of the word, in stream order): the host's own checks have passed by the time it lands

@@ -300,12 +300,13 @@ __device__ __forceinline__ h16_epi_pre h16_epi_fetch(const srk_conv_args& a) {
   return e;
 }
 template <typename T, int MT, int NS, int SAUX>
-__device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane, int tile, int cstamp = 0) {
+__device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane, int tile,
+                                               const h16_u32x4* lsig, int cstamp = 0) {
   typedef typename H16<T>::v8 v8;
   h16_u32x4 sbits = {0u, 0u, 0u, 0u};
   const bool wsigns = (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = (a.flags & SRK_CONV_MASK_SIGNS) != 0;
   h16_u32x4* const sgp = reinterpret_cast<h16_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane;
-  if (msigns) sbits = *sgp;
+  if (msigns) sbits = lsig[wv * 64 + lane];          // (a loader wave fetched the workgroup's 4 KB of bits during the conv: no global round trip here)
   constexpr int TB = NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1);      // rows per batch (loads ahead of stores)
   const int n16 = lane & 15, G = lane >> 4;
   bool cok[2];
@@ -377,9 +378,10 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc
           const int it = 4 * m + 2 * ph + p;                 // item of the lane: sign-bit byte
           float o[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = acc[m][ph][2 * p][e] * alpha;
-            o[4 + e] = acc[m][ph][2 * p + 1][e] * alpha;
+          for (int e = 0; e < 4; ++e) { o[e] = acc[m][ph][2 * p][e]; o[4 + e] = acc[m][ph][2 * p + 1][e]; }
+          if (alpha != 1.f) {          // (wave-uniform: only a block's last conv scales)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= alpha;
           }
 #pragma unroll
           for (int sidx = 0; sidx < NS; ++sidx) {
@@ -912,10 +914,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
   typedef typename H16<T>::v8 v8;
   constexpr int MT = 4;
   typedef HGeo<MT> G;
-  __shared__ float4 smem[2 * G::STAGE4 + 1 + 16];
+  __shared__ float4 smem[2 * G::STAGE4 + 1 + 16 + 256];
   unsigned* const wg_cnt = reinterpret_cast<unsigned*>(smem + 2 * G::STAGE4);
-  volatile unsigned* const wg_go = wg_cnt + 1;           // the census verdict (srk_chain.h): 1 = every workgroup is resident, 2 = give up
   float* const lds_bias = reinterpret_cast<float*>(smem + 2 * G::STAGE4 + 1);      // (M16) the 64 biases of the conv about to start
+  h16_u32x4* const lds_signs = reinterpret_cast<h16_u32x4*>(smem + 2 * G::STAGE4 + 1 + 16);     // (M16) sign bits of the conv in progress: [4 waves][64 lanes]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -941,11 +943,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     const int lw = wv - 4;
     constexpr int NXJ = (G::HPIECES + CH_NLOAD - 1) / CH_NLOAD, NWJ = G::WPIECES / CH_NLOAD;
     const unsigned wvo = (unsigned)(lane * 16);
-    // census, step 1: loader wave 0 counts the workgroup in before anything else (its verdict is due before conv 0's epilogue)
-    int census_in = 1;
-    if (lw == 0 && lane == 0) census_in = srk_chain_census_arrive(A);
     const srk_chain_watch watch = srk_chain_watch_of(A.flags, lane, n, ty, tx, tilesH, tilesW);     // lanes 0..8: the eight neighbouring tiles
-    auto wait_flags = [&](unsigned target) { srk_chain_wait(watch, target, A.err, lane); };
+    // drain: a wait of this launch has run into its bound (here or in another tile) -- no more waiting (srk_chain.h)
+    bool drain = false;
+    auto wait_flags = [&](unsigned target) { if (!drain) drain = !srk_chain_wait(watch, target, A, lane); };
     unsigned xvo[NXJ];
     __amdgpu_buffer_rsrc_t xrs, wrs;
     int CoutP = 64;
@@ -991,7 +992,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     // (M16) the bias of the conv about to start goes through the LDS into the accumulators' initial values: loader wave 0 fetches it in
     // front of the stage that is issued beside it and writes it behind that stage's own vmcnt(0) -- visible behind the barrier that follows
     float bias_v = 0.f;
-    bool bias_pending = false;
+    bool bias_pending = false, sig_pending_l = false;
+    h16_u32x4 sig_v[4];
     auto bias_fetch = [&](const srk_conv_args& a) {
       if (M16 && lw == 0) {
         bias_v = (a.bias && lane < a.Cout) ? a.bias[lane] : 0.f;
@@ -1018,12 +1020,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
           const bool fresh = H16_CHAIN_FRESH_DEV && c > 0 && q + 1 >= nq - 2;    // the slice the previous conv has written
           if (c > 0 && q + 1 == nq - 2) { H16C_STAMP(256, c, 4); wait_flags(A.epoch + (unsigned)c); H16C_STAMP(256, c, 5); }
           stage(q + 1, (q + 1) & 1, fresh || (H16_CHAIN_ALL_DEV && c > 0));
-          if (c == 0 && q == 0 && lw == 0) {
-            // census, step 2, beside the first stage's MFMAs and with stage 1 in flight: wait (bounded) until the whole grid is resident.
-            // The verdict goes through the LDS; every wave reads it behind the last stage barrier of conv 0 (>= one barrier from here),
-            // i.e. before the first store and before the first flag wait of the launch.
-            if (lane == 0) { *wg_go = srk_chain_census_wait(A, census_in) ? 1u : 2u; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (M16 && q == 0 && lw == CH_NLOAD - 1 && (A.c[c].flags & SRK_CONV_MASK_SIGNS)) {
+            // the LeakyReLU' sign bits this conv's epilogue masks with: 16 bytes per lane of the four MFMA waves
+            const h16_u32x4* sg = reinterpret_cast<const h16_u32x4*>(A.c[c].signs) + (long)tile * 256 + lane;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sig_v[w] = sg[w * 64];
+            sig_pending_l = true;
           }
           if (c > 0 && q == 0 && lw == 0) {
             // publish conv c - 1 of this tile: once the four MFMA waves have seen their stores acknowledged (they count themselves in
@@ -1040,9 +1042,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bias_put();           // (the next conv's bias: the MFMA waves read it behind THIS barrier, in front of their accumulators' reset)
+        if (M16 && sig_pending_l) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) lds_signs[w * 64 + lane] = sig_v[w];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          sig_pending_l = false;
+        }
         __builtin_amdgcn_s_barrier();
       }
-      if (c == 0 && *wg_go != 1u) return;              // census failed: all six waves leave here (the MFMA waves in front of their epilogue)
     }
     return;
   }
@@ -1192,12 +1199,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       H16C_STAMP(0, c, 1);
-      if (c == 0 && *wg_go != 1u) return;                // census (srk_chain.h): the grid is not resident -- nothing has been stored
       const int n_aux = (ep.r1 ? 1 : 0) + (ep.r2 ? 1 : 0) + (ep.mask ? 1 : 0);
-      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
-      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
-      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
-      else h16_epilogue16<T, MT, 3, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, c);
+      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else h16_epilogue16<T, MT, 3, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
       H16C_STAMP(0, c, 2);
       sig_pending = c + 1 < nconv;
     }
@@ -1317,7 +1323,6 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     H16C_STAMP(0, c, 1);
-    if (c == 0 && *wg_go != 1u) return;                // census (srk_chain.h): the grid is not resident -- nothing has been stored
     const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
     if (n_aux == 0) h16_epilogue<T, MT, 0, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);
     else if (n_aux == 1) h16_epilogue<T, MT, 1, false, STORE_AUX>(a, acc, ls, n, oh0, ow0, 0, wv, lane, tile);

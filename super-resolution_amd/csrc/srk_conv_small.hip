@@ -61,8 +61,17 @@ __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const srk_conv_a
   float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) bq = *reinterpret_cast<const float4*>(a.bias + 4 * q);
 
+  // XCD-contiguous tile ranges (round 4): workgroup b runs on XCD b & 7, and each XCD has its own L2.  With tile = b, b + grid, ... the two
+  // 16-pixel tiles that share a 128-byte line of an image row, and the tiles that share halo rows, landed on different XCDs: every L2
+  // fetched the same lines again (PMC, Cin = 1 at 256 x 256: 67.8 MB fetched for 8.4 MB of input).  Now XCD x walks tiles
+  // [x T8, (x + 1) T8) with its gridDim / 8 workgroups.
   int buf = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+  const bool xcd = (gridDim.x & 7) == 0;
+  const int T8 = (ntiles + 7) >> 3;
+  const int t_first = xcd ? (int)(blockIdx.x & 7) * T8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_step = xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_end = xcd ? (((int)(blockIdx.x & 7) + 1) * T8 < ntiles ? ((int)(blockIdx.x & 7) + 1) * T8 : ntiles) : ntiles;
+  for (int tile = t_first; tile < t_end; tile += t_step, buf ^= 1) {
     int bid = tile;
     const int tx = bid % tilesW; bid /= tilesW;
     const int ty = bid % tilesH; bid /= tilesH;

@@ -32,9 +32,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef W42_CH_PREFETCH1
 #define W42_CH_PREFETCH1 0       // 1: chain form of the 16-row kernel: prefetch across the link boundary (PF in wino42_body).  It has the registers
 #endif                           // (no spill), so this is what the 32-row kernel could gain: block 276.0 -> 273.9 / 284.8 -> 277.7 us, step 60.9 -> 61.5 ms
-#ifndef W42_CENSUS
-#define W42_CENSUS 1             // timing-only switch: 0 = the chain kernels without their census (srk_chain.h), 2 = count in but do not wait
-#endif
 #ifndef W42_CHAIN_SKEW_NS
 #define W42_CHAIN_SKEW_NS 0      // default start skew per phase of the chain kernels (srk_chain.h: srk_chain_skew); SRK_W42_CHAIN_SKEW_NS / _GROUPS override
 #endif
@@ -80,9 +77,10 @@ __device__ unsigned long long* g_w42_stamps = nullptr;
 // neighbouring tiles' flags of conv c - 1.
 // PF (chain form of the 16-row kernel, which has registers to spare -- 428 of 512): a link fetches its successor's first halo chunk and
 // first weights in front of its own epilogue (carryP0 = the kernel's copy of those weights); the 32-row kernel cannot afford it.
-// Returns false only as link 0 of a chain whose census failed (srk_chain.h: the grid is not resident; nothing has been stored).
+// drain (CHAIN): a wait of this launch has run into its bound, here or in another tile (srk_chain.h) -- no more waiting in this or any later link.
 template <int MODE, int NMT, bool CHAIN = false>
-__device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0, f32x2 (*carryP0)[6][2] = nullptr) {
+__device__ __forceinline__ void wino42_body(const srk_conv_args& a, const srk_chain_args* A = nullptr, int c = 0, f32x2 (*carryP0)[6][2] = nullptr,
+                                            bool* drain = nullptr) {
   constexpr bool PF = CHAIN && NMT == 1 && W42_CH_PREFETCH1 != 0;
   constexpr int TH = 16 * NMT, IH = TH + 2, IW = SRK_TW + 2;
   constexpr int HS4 = NMT == 2 ? 640 : 384;         // slots per k-half: 37 per row pair (17 resp. 9 pairs), padded to whole instructions
@@ -102,12 +100,6 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
   // the K loop, where there is not one register to spare: the allocator then spills accumulator tiles inside the loop)
   if constexpr (CHAIN) asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63;
-  // CHAIN, link 0: the census (srk_chain.h).  Thread 0 counts the workgroup in before anything else; its verdict is needed in front of the
-  // K loop (below), by which time -- the halo address arithmetic and the first chunk's flight lie in between -- every workgroup of a
-  // resident grid has long arrived, so the wait costs one load that returns beside the first chunk.
-  __shared__ unsigned census_go;
-  int census_in = 1;
-  if constexpr (CHAIN && W42_CENSUS != 0) { if (c == 0 && tid == 0) census_in = srk_chain_census_arrive(*A); }
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // = row position p of this wave
   const int hl = lane >> 5, l32 = lane & 31;
   const int tilesW = (a.OW + SRK_TW - 1) / SRK_TW, tilesH = (a.OH + TH - 1) / TH;
@@ -126,7 +118,7 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
   W42_STAMP(0);
   // CHAIN: the first DMA of a chunk of the last 64 channels (chunks nq - 8 ..) is piece 0 of chunk nq - 8, issued in chunk nq - 10
   const int qwait = nq - 10;
-  bool waited_ok = true;
+  int wait_rc = 0;               // (CHAIN) 1: this wave's flag wait ran into its bound, 2: another tile has given up
 
   // ---- halo DMA plan: instruction i = wv + 4 j (j = 0..4) fills slots 64 i .. 64 i + 63
   constexpr unsigned OOB = 0x80000000u;
@@ -393,9 +385,6 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
     if constexpr (NPC == 5) { piece(0, 0, I3{}); piece(0, 0, I4{}); }
   }
   W42_STAMP(1);
-  if constexpr (CHAIN && W42_CENSUS == 1) {
-    if (c == 0 && tid == 0) census_go = srk_chain_census_wait(*A, census_in) ? 1u : 2u;      // (visible behind the barrier below)
-  }
   __builtin_amdgcn_sched_barrier(0);          // the accumulators are cleared while the first chunks are in flight
 #pragma unroll
   for (int t = 0; t < 12 * NMT; ++t)
@@ -412,10 +401,6 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
-  if constexpr (CHAIN && W42_CENSUS == 1) {
-    // the grid is not resident (census): leave before anything is stored or waited for; every workgroup of the launch takes this exit
-    if (c == 0 && *reinterpret_cast<volatile unsigned*>(&census_go) != 1u) return false;
   }
   W42_STAMP(2);
   if constexpr (LDSW) {
@@ -444,7 +429,7 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
         chunk(q, I0{});
         chunk(q + 1, I1{});
       }
-      if (c > 0) waited_ok = srk_chain_wait_scalar(A->flags, n, ty, tx, tilesH, tilesW, A->epoch + (unsigned)c);
+      if (c > 0 && !*drain) wait_rc = srk_chain_wait_scalar(A->flags, A->poison, A->wait_ticks, n, ty, tx, tilesH, tilesW, A->epoch + (unsigned)c);
     }
     for (; q + 1 < nq; q += 2) {
       chunk(q, I0{});
@@ -534,12 +519,12 @@ __device__ __forceinline__ bool wino42_body(const srk_conv_args& a, const srk_ch
     //  the next conv's first halo chunk issued in front of this epilogue 480 / 496, + its first weights 508 / 522, both behind the
     //  epilogue 481 / 495, the flag raised inside the next conv's K loop instead of here 465 / 480 -- whatever stays live across the
     //  conv boundary costs this kernel more in spills than the overlap returns.)
-    if (!waited_ok && lane == 0) __hip_atomic_store(A->err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (wait_rc == 1 && lane == 0) srk_chain_give_up(*A);          // (every wave polls for itself: whichever of them ran out of time says so)
+    if (wait_rc != 0) *drain = true;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (tid == 0 && c + 1 < A->n) __hip_atomic_store(A->flags + tile, A->epoch + (unsigned)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  return true;
 }
 
 template <int MODE, int NMT>
@@ -553,9 +538,8 @@ template <int NMT>
 __global__ __launch_bounds__(256) void conv3x3_f32_wino42_chain_kernel(const srk_chain_args A) {
   f32x2 P0[6][2];          // (16-row form: the next conv's first weights, fetched by the previous link)
   srk_chain_skew(A);
-  for (int c = 0; c < A.n; ++c) {
-    if (!wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0)) return;
-  }
+  bool drain = false;
+  for (int c = 0; c < A.n; ++c) wino42_body<SRK_IN_PLAIN, NMT, true>(A.c[c], &A, c, &P0, &drain);
 }
 
 }  // namespace

@@ -140,10 +140,10 @@ class Stepper:
             self.generator._engine.enable_grad_sync()      # (module-wise generators: gradients go through _sync_grads)
         if distributed:
             _stat_group()          # (created by every rank at the same point)
-            # census bound of the chain forms (include/srk.h): a collective's kernel holds CUs while a peer rank is late -- seconds in a
-            # first iteration -- and a chain launch behind it has to wait that out; giving up after 50 ms would end the job (see step())
-            if "SRK_CHAIN_ENTRY_MS" not in os.environ and torch.device(device).type == "cuda":
-                L.lib().srk_chain_set_entry_us(30_000_000)
+            # wait bound of the chain forms (include/srk.h): a collective's kernel holds CUs while a peer rank is late -- seconds in a
+            # first iteration -- and a tile behind it has to wait that out; giving up after 50 ms would end the job (see step())
+            if "SRK_CHAIN_WAIT_MS" not in os.environ and torch.device(device).type == "cuda":
+                L.lib().srk_chain_set_wait_us(30_000_000)
             self.shared_gpu = _ranks_share_a_gpu(device)
             if self.shared_gpu:
                 # The chain forms need the whole GPU: two ranks' 256-tile persistent launches would split the CUs and both give up at
@@ -212,7 +212,7 @@ class Stepper:
     def step(self, imgs_lr, imgs_hr):
         """One iteration.  A dense block's convolutions may go out as ONE persistent launch (the chain forms, include/srk.h), which needs
         every workgroup of that launch resident at once.  If one gave up -- a foreign process on the GPU, a kernel holding CUs beyond
-        the census bound -- the library has stored nothing from it, every optimizer step since has skipped itself on the device, and
+        the wait bound -- its results are garbage in activation buffers, every optimizer step since has skipped itself on the device, and
         the first library call that notices raises ChainTimeout: recover (device-wide wait, fault cleared, chain forms rested) and run
         the iteration again, conv by conv.  What iterations in between returned as losses is undefined; weights and optimizer state
         are those of the last good iteration (a discriminator whose step ran beside the failing launch may see this batch twice)."""
@@ -223,7 +223,7 @@ class Stepper:
                 return self.gan_step(imgs_lr, imgs_hr)
             except L.ChainTimeout:
                 # data parallel: the other ranks are inside this iteration's collectives; a rank that started over on its own would
-                # pair its all-reduces with the wrong ones.  There the census bound is 30 s (below), so this is a fault, not a busy GPU.
+                # pair its all-reduces with the wrong ones.  There the wait bound is 30 s (below), so this is a fault, not a busy GPU.
                 if attempt == 2 or self.distributed:
                     raise
                 self.recover_chain_fault()

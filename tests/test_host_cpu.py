@@ -355,38 +355,36 @@ def test_unknown_and_ignored_options_are_reported_once(capsys):
 def test_chain_epoch_wrap_arithmetic(srk):
     """csrc/srk_chain.h: a chain kernel's tile flags hold `epoch + k + 1` in 32 bits, never reset per launch, and a waiter tests
     (int)(flag - target) >= 0.  That is only right while every live value is within 2^31 of every target: srk_chain_epoch_plan zeroes the
-    flags (and the census count) before either would pass 2^30.  Pure host arithmetic, no GPU: replay launches across the wrap with
-    randomly used tiles and check that a flag a tile left behind ANY number of launches ago never reads as "published" for a later launch,
-    and that what the launch itself publishes always does."""
+    flags before the epoch would pass 2^30.  Pure host arithmetic, no GPU: replay launches across the wrap with randomly used tiles and
+    check that a flag a tile left behind ANY number of launches ago never reads as "published" for a later launch, and that what the
+    launch itself publishes always does."""
     import ctypes as C
     import random
     lib = srk._lib.lib()
-    eo, ao, rs = C.c_uint(0), C.c_uint(0), C.c_int(0)
+    eo, rs = C.c_uint(0), C.c_int(0)
 
-    def plan(epoch, base, n, tiles):
-        assert lib.srk_chain_epoch_plan(epoch, base, n, tiles, C.byref(eo), C.byref(ao), C.byref(rs)) == 0
-        return eo.value, ao.value, rs.value
-    assert plan(0, 0, 5, 256) == (0, 0, 0)
-    assert plan((1 << 30) - 5, 10, 5, 256) == (0, 0, 1)            # epoch + n would reach 2^30
-    assert plan((1 << 30) - 6, 10, 5, 256) == ((1 << 30) - 6, 10, 0)
-    assert plan(100, (1 << 30) - 256, 5, 256) == (0, 0, 1)         # the census count would
-    assert lib.srk_chain_epoch_plan(0, 0, 9, 256, C.byref(eo), C.byref(ao), C.byref(rs)) != 0      # more convs than a launch holds
-    assert lib.srk_chain_epoch_plan(0, 0, 5, 2000, C.byref(eo), C.byref(ao), C.byref(rs)) != 0     # more tiles than flags
+    def plan(epoch, n):
+        assert lib.srk_chain_epoch_plan(epoch, n, C.byref(eo), C.byref(rs)) == 0
+        return eo.value, rs.value
+    assert plan(0, 5) == (0, 0)
+    assert plan((1 << 30) - 5, 5) == (0, 1)            # epoch + n would reach 2^30
+    assert plan((1 << 30) - 6, 5) == ((1 << 30) - 6, 0)
+    assert lib.srk_chain_epoch_plan(0, 9, C.byref(eo), C.byref(rs)) != 0      # more convs than a launch holds
 
     def ready(flag, target):          # the kernels' test, in 32-bit arithmetic
         d = (flag - target) & 0xffffffff
         return d < 0x80000000
     rnd = random.Random(7)
     flags = [0] * 1024
-    epoch, base = (1 << 30) - 4000, (1 << 30) - 90000
+    epoch = (1 << 30) - 4000
     resets = 0
     for launch in range(3000):
         n, tiles = rnd.randint(2, 8), rnd.choice([1, 7, 64, 256, 1000])
-        epoch, base, reset = plan(epoch, base, n, tiles)
+        epoch, reset = plan(epoch, n)
         if reset:
             flags = [0] * 1024
             resets += 1
-        assert epoch + n <= (1 << 30) and base + tiles <= (1 << 30)
+        assert epoch + n <= (1 << 30)
         for k in range(1, n):         # conv k waits for its neighbours' conv k - 1: target = epoch + k
             tgt = (epoch + k) & 0xffffffff
             # whatever earlier launches left in ANY flag is not mistaken for this launch's conv k - 1 ...
@@ -396,7 +394,4 @@ def test_chain_epoch_wrap_arithmetic(srk):
                 flags[t] = (epoch + k + 1) & 0xffffffff
                 assert ready(flags[t], (epoch + k + 1) & 0xffffffff)
         epoch += n
-        base += tiles
     assert resets >= 1
-    # the census word carries a poison bit (bit 31): its count must stay clear of it
-    assert base < (1 << 31)
