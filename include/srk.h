@@ -164,6 +164,9 @@ int srk_chain_set_wait_us(unsigned us);
 int srk_debug_chain_set(unsigned epoch, long off_calls);
 int srk_debug_chain_inject_fault(unsigned code);
 int srk_debug_chain_inject_fault_async(void* stream);     /* the same from the device side of `stream`, in stream order */
+/* start skew of a chain kernel kind (0: 16-bit, 1: fp32): workgroup b begins (b >> 3) % groups * ns late (experiment: spreading the
+ * epilogues' store bursts, measured without effect; test aid: tiles whose neighbours are late, deterministically) */
+int srk_debug_chain_skew(int kind, unsigned ns, unsigned groups);
 int srk_debug_hold_cus(int workgroups, int usec, void* stream);
 
 /* Weight-gradient of the same convolution:

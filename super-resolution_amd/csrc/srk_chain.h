@@ -134,9 +134,8 @@ bool srk_chain_flags_uncached();           // the flag array is uncached memory 
 // Claims the device for one chain launch of `tiles` workgroups on `st`: 1 = go (A->epoch / flags / err / poison / wait bound filled for n convs,
 // `st` ordered behind the previous chain launch; call srk_chain_end afterwards), 0 = not now (stream capture, forms switched off or backing
 // off after a time-out), < 0 = error (SRK_ERR_CHAIN_TIMEOUT: an earlier launch timed out and srk_chain_recover has not been called)
-int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A);
-// start skew of a chain kernel kind ("H16" / "W42"): SRK_<kind>_CHAIN_SKEW_NS (per phase) and SRK_<kind>_CHAIN_SKEW_GROUPS (phases)
-void srk_chain_skew_of(const char* kind, unsigned dflt_ns, unsigned dflt_groups, srk_chain_args* A);
+// kind: 0 = the 16-bit kernel, 1 = the fp32 F(2x4,3x3) kernel (start skew: SRK_H16_ / SRK_W42_CHAIN_SKEW_NS, _GROUPS; srk_debug_chain_skew)
+int srk_chain_begin(hipStream_t st, int n, int tiles, int kind, srk_chain_args* A);
 int srk_chain_end(hipStream_t st, bool launched);
 // true while the chain forms rest after a recovered time-out (sequences go conv by conv); tick: this is a launch attempt, count it off
 bool srk_chain_resting(bool tick);

@@ -19,6 +19,8 @@ struct ChainDev {
   int strikes = 0;             // time-outs recovered from so far
   long off_calls = 0;          // srk_chain_begin calls that still answer "not now" (back-off after a recovered time-out)
   unsigned long long launches = 0, resets = 0;
+  unsigned skew_ns[2] = {0, 0}, skew_groups[2] = {1, 1};      // start skew per kernel kind (0: 16-bit, 1: fp32): srk_chain_skew
+  bool skew_read = false;
 };
 ChainDev g_dev[16];
 std::mutex g_mu;
@@ -92,6 +94,23 @@ const unsigned* srk_chain_fault_word() {
   return g_dev[dev].err;
 }
 
+namespace {
+void skew_from_env(ChainDev* D) {
+  static const char* names[2] = {"H16", "W42"};
+  for (int k = 0; k < 2; ++k) {
+    char name[64];
+    snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_NS", names[k]);
+    const char* e = getenv(name);
+    unsigned ns = e ? (unsigned)atoi(e) : 0u;
+    snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_GROUPS", names[k]);
+    e = getenv(name);
+    unsigned g = e ? (unsigned)atoi(e) : 4u;
+    if (g < 2 || g > 64 || ns > 1000000) { ns = 0; g = 1; }
+    D->skew_ns[k] = ns; D->skew_groups[k] = g;
+  }
+  D->skew_read = true;
+}
+}  // namespace
 // back-off after a recovered time-out: true while the chain forms rest (srk_chain_recover); `tick` counts one sequence call off
 bool srk_chain_resting(bool tick) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -103,7 +122,7 @@ bool srk_chain_resting(bool tick) {
   return true;
 }
 
-int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A) {
+int srk_chain_begin(hipStream_t st, int n, int tiles, int kind, srk_chain_args* A) {
   g_mu.lock();
   ChainDev* D = chain_dev();
   if (!D) { g_mu.unlock(); return 0; }
@@ -147,21 +166,21 @@ int srk_chain_begin(hipStream_t st, int n, int tiles, srk_chain_args* A) {
   (void)tiles;
   A->n = n; A->epoch = D->epoch; A->flags = D->flags; A->err = D->err;
   A->poison = D->flags + SRK_CHAIN_FLAGS; A->wait_ticks = D->wait_ticks;
-  A->skew_ticks = 0; A->skew_groups = 1;
+  if (!D->skew_read) skew_from_env(D);
+  A->skew_ticks = D->skew_ns[kind & 1] / 10; A->skew_groups = D->skew_groups[kind & 1];
   D->epoch += (unsigned)n;
   return 1;
 }
 
-void srk_chain_skew_of(const char* kind, unsigned dflt_ns, unsigned dflt_groups, srk_chain_args* A) {
-  char name[64];
-  snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_NS", kind);
-  const char* e = getenv(name);
-  unsigned ns = e ? (unsigned)atoi(e) : dflt_ns;
-  snprintf(name, sizeof name, "SRK_%s_CHAIN_SKEW_GROUPS", kind);
-  e = getenv(name);
-  unsigned g = e ? (unsigned)atoi(e) : dflt_groups;
-  if (g < 2 || g > 64 || ns > 100000) { ns = 0; g = 1; }
-  A->skew_ticks = ns / 10; A->skew_groups = g;
+// test aid / experiment: start skew of a chain kernel kind (0: 16-bit, 1: fp32 F(2x4,3x3)): workgroup b starts (b >> 3) % groups * ns late
+extern "C" int srk_debug_chain_skew(int kind, unsigned ns, unsigned groups) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  ChainDev* D = chain_dev();
+  if (!D || kind < 0 || kind > 1) return SRK_ERR_UNSUPPORTED;
+  if (!D->skew_read) skew_from_env(D);
+  if (groups < 2 || groups > 64 || ns > 1000000) { ns = 0; groups = 1; }
+  D->skew_ns[kind] = ns; D->skew_groups[kind] = groups;
+  return SRK_OK;
 }
 
 int srk_chain_end(hipStream_t st, bool launched) {

@@ -897,9 +897,7 @@ typedef srk_chain_args h16_chain_args;
 #ifndef CH_NLOAD_N
 #define CH_NLOAD_N 2
 #endif
-#ifndef H16_CHAIN_SKEW_NS
-#define H16_CHAIN_SKEW_NS 0          // default start skew per phase (srk_chain_skew); SRK_H16_CHAIN_SKEW_NS / _GROUPS override
-#endif
+
 constexpr int CH_NLOAD = CH_NLOAD_N, CH_THREADS = 64 * (4 + CH_NLOAD);      // loader waves of the chain kernel
 // M16 (round 4, the default: H16_CHAIN_M16): the MFMA waves run v_mfma_f32_16x16x32 instead of 32x32x16 -- the same staging, the same LDS
 // image, the same number of fragment reads (72 per stage and wave) and the same MFMA cycles (288 x 16), but
@@ -1526,12 +1524,9 @@ int srk_launch_conv_h16_chain(const srk_conv_args* args, int n, hipStream_t st) 
   srk_chain_args A;
   const srk_conv_args& f = args[0];
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16) * srk_div_up(f.W, HW_TW)));
-  const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
+  const int rc = srk_chain_begin(st, n, (int)grid.x, 0, &A);
   if (rc != 1) return rc;
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
-  static unsigned sk_ns = ~0u, sk_g = 0;          // (the environment is read once)
-  if (sk_ns == ~0u) { srk_chain_skew_of("H16", H16_CHAIN_SKEW_NS, 4, &A); sk_ns = A.skew_ticks; sk_g = A.skew_groups; }
-  A.skew_ticks = sk_ns; A.skew_groups = sk_g;
   if (h16_chain_m16()) {
     if (f.wp_format == 7) hipLaunchKernelGGL((conv3x3_h16_chain_kernel<_Float16, true>), grid, dim3(CH_THREADS), 0, st, A);
     else hipLaunchKernelGGL((conv3x3_h16_chain_kernel<__bf16, true>), grid, dim3(CH_THREADS), 0, st, A);

@@ -32,9 +32,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef W42_CH_PREFETCH1
 #define W42_CH_PREFETCH1 0       // 1: chain form of the 16-row kernel: prefetch across the link boundary (PF in wino42_body).  It has the registers
 #endif                           // (no spill), so this is what the 32-row kernel could gain: block 276.0 -> 273.9 / 284.8 -> 277.7 us, step 60.9 -> 61.5 ms
-#ifndef W42_CHAIN_SKEW_NS
-#define W42_CHAIN_SKEW_NS 0      // default start skew per phase of the chain kernels (srk_chain.h: srk_chain_skew); SRK_W42_CHAIN_SKEW_NS / _GROUPS override
-#endif
 #ifndef W42_CHAIN_SIGNS
 #define W42_CHAIN_SIGNS 0        // 1: sign bits (srk_conv_args.signs) in the chain kernels.  Correct (bit-identical to the mask tensors), but with
 #endif                           // them compiled in the 32-row chain kernel spills 131 registers around its exchange / epilogue: 455 -> 490 us per block
@@ -628,12 +625,9 @@ int srk_launch_conv_w42_chain(const srk_conv_args* args, int n, hipStream_t st) 
   const srk_conv_args& f = args[0];
   const int nmt = srk_conv_wino42_nmt(f);
   const dim3 grid((unsigned)(f.N * srk_div_up(f.H, 16 * nmt) * srk_div_up(f.W, SRK_TW)));
-  const int rc = srk_chain_begin(st, n, (int)grid.x, &A);
+  const int rc = srk_chain_begin(st, n, (int)grid.x, 1, &A);
   if (rc != 1) return rc;
   for (int c = 0; c < n; ++c) A.c[c] = args[c];
-  static unsigned sk_ns = ~0u, sk_g = 0;
-  if (sk_ns == ~0u) { srk_chain_skew_of("W42", W42_CHAIN_SKEW_NS, 4, &A); sk_ns = A.skew_ticks; sk_g = A.skew_groups; }
-  A.skew_ticks = sk_ns; A.skew_groups = sk_g;
   if (nmt == 2) hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<2>, grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL(conv3x3_f32_wino42_chain_kernel<1>, grid, dim3(256), 0, st, A);
   const bool ok = hipGetLastError() == hipSuccess;
