@@ -36,6 +36,12 @@ typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef H16_STORE_AUX
 #define H16_STORE_AUX 16
 #endif
+// 16x16x32 chain epilogue: 1 = the two 64-byte halves of a pixel's 128-byte line meet in ONE store instruction (two DPP row shifts per
+// dword), 0 (default) = two half-line store instructions.  Interleaved same-box A/B (tools/debug/build_h16_var.sh,
+// profiles/r04_ab_h16_epilogue_full_vs_half_lines.txt): dominant kernel of the c4 step 127.5-128.7 us (1) vs 126.1-128.7 (0), HBM traffic equal
+#ifndef H16_EPI_FULL_LINES
+#define H16_EPI_FULL_LINES 0
+#endif
 
 namespace {
 
@@ -281,28 +287,29 @@ __device__ __forceinline__ void h16_epilogue(const srk_conv_args& a, f32x16 (&ac
 // The accumulators START at the bias (conv3x3_h16_chain_kernel stages it through the LDS), so the output is acc * alpha; and every scalar the
 // epilogue needs was fetched when the conv began (h16_epi_pre): stamps showed 1.9-2.2 us of a 4.8 us epilogue going to the argument loads
 // and the bias round trip, with the matrix pipes idle.
-struct h16_epi_pre {
-  const float *y, *r1, *r2, *mask;
+struct h16_epi_pre {            // (13 scalar registers across the conv.  All 27 the epilogue can need -- the residual / mask views too -- did not fit:
+  const float* y;               //  the allocator spilled them, through vector registers, to SCRATCH: 43 MB of stores per dense block, PMC)
   void* signs;
-  int y_ldc, y_coff, r1_ldc, r1_coff, r2_ldc, r2_coff, m_ldc, m_coff, OH, OW, Cout, flags;
-  float alpha, beta1, beta2, slope, mask_slope;
+  int y_ldc, y_coff, OH, OW, Cout, flags;
+  float alpha, slope, mask_slope;
 };
 __device__ __forceinline__ h16_epi_pre h16_epi_fetch(const srk_conv_args& a) {
   h16_epi_pre e;
-  e.y = a.y; e.r1 = a.r1; e.r2 = a.r2; e.mask = a.mask; e.signs = a.signs;
-  e.y_ldc = a.y_ldc; e.y_coff = a.y_coff; e.r1_ldc = a.r1_ldc; e.r1_coff = a.r1_coff; e.r2_ldc = a.r2_ldc; e.r2_coff = a.r2_coff;
-  e.m_ldc = a.m_ldc; e.m_coff = a.m_coff; e.OH = a.OH; e.OW = a.OW; e.Cout = a.Cout; e.flags = a.flags;
-  e.alpha = a.alpha; e.beta1 = a.beta1; e.beta2 = a.beta2; e.slope = a.slope; e.mask_slope = a.mask_slope;
+  e.y = a.y; e.signs = a.signs;
+  e.y_ldc = a.y_ldc; e.y_coff = a.y_coff; e.OH = a.OH; e.OW = a.OW; e.Cout = a.Cout; e.flags = a.flags;
+  e.alpha = a.alpha; e.slope = a.slope; e.mask_slope = a.mask_slope;
   // (pinned in scalar registers HERE: left alone, the compiler loads each field where it is first used -- in the epilogue)
-  asm volatile("" : "+s"(e.y), "+s"(e.r1), "+s"(e.r2), "+s"(e.mask), "+s"(e.signs));
-  asm volatile("" : "+s"(e.y_ldc), "+s"(e.y_coff), "+s"(e.r1_ldc), "+s"(e.r1_coff), "+s"(e.r2_ldc), "+s"(e.r2_coff), "+s"(e.m_ldc), "+s"(e.m_coff));
-  asm volatile("" : "+s"(e.OH), "+s"(e.OW), "+s"(e.Cout), "+s"(e.flags), "+s"(e.alpha), "+s"(e.beta1), "+s"(e.beta2), "+s"(e.slope), "+s"(e.mask_slope));
+  asm volatile("" : "+s"(e.y), "+s"(e.signs), "+s"(e.y_ldc), "+s"(e.y_coff), "+s"(e.OH), "+s"(e.OW));
+  asm volatile("" : "+s"(e.Cout), "+s"(e.flags), "+s"(e.alpha), "+s"(e.slope), "+s"(e.mask_slope));
   return e;
 }
 template <typename T, int MT, int NS, int SAUX>
-__device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane, int tile,
-                                               const h16_u32x4* lsig, int cstamp = 0) {
+__device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, const srk_conv_args& ax, f32x4 (&acc)[MT][2][4], int n, int oh0, int ow0, int wv, int lane,
+                                               int tile, const h16_u32x4* lsig, int cstamp = 0) {
   typedef typename H16<T>::v8 v8;
+  // (everything derived from the lane id is formed HERE, from a copy the compiler cannot see through: hoisted out of the conv loop these
+  // values live across the stage loops, where every register is taken, and come back from scratch in the middle of the epilogue)
+  asm volatile("" : "+v"(lane));
   h16_u32x4 sbits = {0u, 0u, 0u, 0u};
   const bool wsigns = (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = (a.flags & SRK_CONV_MASK_SIGNS) != 0;
   h16_u32x4* const sgp = reinterpret_cast<h16_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane;
@@ -312,8 +319,9 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc
   bool cok[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) cok[p] = 32 * p + 8 * G + 7 < a.Cout;
-  const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr;
-  const float alpha = a.alpha, beta1 = a.beta1, beta2 = a.beta2, slope = a.slope, mask_slope = a.mask_slope;
+  // (the residual / mask views of the few convs that have any -- a block's last conv; data gradients without sign bits -- are read here)
+  const bool has_r1 = NS > 0 && ax.r1 != nullptr, has_r2 = NS > 0 && ax.r2 != nullptr;
+  const float alpha = a.alpha, beta1 = ax.beta1, beta2 = ax.beta2, slope = a.slope, mask_slope = a.mask_slope;
   const long img_px = (long)a.OH * a.OW;
   auto rsrc16 = [&](const float* p, int ldc, int coff) {
     const T* q = reinterpret_cast<const T*>(p) + (long)n * img_px * ldc + coff;
@@ -326,21 +334,21 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc
   bool sres[NS > 0 ? NS : 1];
   if constexpr (NS >= 1) {
     const bool m0 = !has_r1 && !has_r2;
-    srs[0] = rsrc16(has_r1 ? a.r1 : (has_r2 ? a.r2 : a.mask), has_r1 ? a.r1_ldc : (has_r2 ? a.r2_ldc : a.m_ldc), has_r1 ? a.r1_coff : (has_r2 ? a.r2_coff : a.m_coff));
-    sld[0] = has_r1 ? a.r1_ldc : (has_r2 ? a.r2_ldc : a.m_ldc);
+    srs[0] = rsrc16(has_r1 ? ax.r1 : (has_r2 ? ax.r2 : ax.mask), has_r1 ? ax.r1_ldc : (has_r2 ? ax.r2_ldc : ax.m_ldc), has_r1 ? ax.r1_coff : (has_r2 ? ax.r2_coff : ax.m_coff));
+    sld[0] = has_r1 ? ax.r1_ldc : (has_r2 ? ax.r2_ldc : ax.m_ldc);
     scoef[0] = has_r1 ? beta1 : (has_r2 ? beta2 : 0.f);
     sms[0] = m0 ? mask_slope : 1.f; sres[0] = !m0;
   }
   if constexpr (NS >= 2) {
     const bool is2 = has_r1 && has_r2;
-    srs[1] = rsrc16(is2 ? a.r2 : a.mask, is2 ? a.r2_ldc : a.m_ldc, is2 ? a.r2_coff : a.m_coff);
-    sld[1] = is2 ? a.r2_ldc : a.m_ldc;
+    srs[1] = rsrc16(is2 ? ax.r2 : ax.mask, is2 ? ax.r2_ldc : ax.m_ldc, is2 ? ax.r2_coff : ax.m_coff);
+    sld[1] = is2 ? ax.r2_ldc : ax.m_ldc;
     scoef[1] = is2 ? beta2 : 0.f;
     sms[1] = is2 ? 1.f : mask_slope; sres[1] = is2;
   }
   if constexpr (NS >= 3) {
-    srs[2] = rsrc16(a.mask, a.m_ldc, a.m_coff);
-    sld[2] = a.m_ldc; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
+    srs[2] = rsrc16(ax.mask, ax.m_ldc, ax.m_coff);
+    sld[2] = ax.m_ldc; scoef[2] = 0.f; sms[2] = mask_slope; sres[2] = false;
   }
   H16C_STAMP(0, cstamp, 3);            // (stamped build: set-up of the epilogue done)
 #pragma unroll
@@ -372,7 +380,8 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc
     for (int mm = 0; mm < TB; ++mm) {
       const int m = m0 + mm;
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
+      for (int ph = 0; ph < 2; ++ph) {
+        h16_u32x4 hw[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const int it = 4 * m + 2 * ph + p;                 // item of the lane: sign-bit byte
@@ -420,9 +429,42 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, f32x4 (&acc
             for (int e = 0; e < 8; ++e) byte |= (back[e] > 0.f ? 1u : 0u) << e;
             sbits[it >> 2] |= (ok ? byte : 0u) << (8 * (it & 3));
           }
-          const unsigned off = ok ? (unsigned)(pix[mm][ph] * a.y_ldc + 32 * p + 8 * G) * 2u : H_OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h16_u32x4, hv), yrs, off, 0, SAUX);
+          hw[p] = __builtin_bit_cast(h16_u32x4, hv);
         }
+        // FULL-LINE STORES.  The lane (n16, G) holds channels 8 G .. of half p = 0 and 32 + 8 G .. of half p = 1 of pixel n16: stored as they
+        // are, an instruction writes 64 of a pixel's 128 bytes.  Here the two halves of a pixel first meet in ONE instruction: lanes
+        // n16 >= 8 hand their p = 0 half to lane n16 - 8's partner slot and take over the p = 1 half of pixel n16 - 8 (two DPP row shifts by 8
+        // within the 16-lane row that shares G): store 1 then writes the whole 128-byte line of pixels 0 .. 7, store 2 of pixels 8 .. 15.
+        // (Built on the suspicion that half-line write-through stores were behind 127.8 MB of writes per block for 88 MB of outputs; they
+        // were not -- that was a 27-dword argument struct spilled to scratch by every lane, see h16_epi_pre -- the traffic is the same
+        // either way.  Kept as a switch; LOG.md has the A/B.)
+#if H16_EPI_FULL_LINES
+        h16_u32x4 d1, d2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // row_shr:8 (0x118): lane i reads lane i - 8 of its row; bank_mask 0xc: only lanes 8 .. 15 are written, lanes 0 .. 7 keep `old`
+          d1[k] = (unsigned)__builtin_amdgcn_update_dpp((int)hw[0][k], (int)hw[1][k], 0x118, 0xf, 0xc, false);
+          // row_shl:8 (0x108): lane i reads lane i + 8; bank_mask 0x3: only lanes 0 .. 7 are written
+          d2[k] = (unsigned)__builtin_amdgcn_update_dpp((int)hw[1][k], (int)hw[0][k], 0x108, 0xf, 0x3, false);
+        }
+        {
+          const int oh = oh0 + MT * wv + m, owa = ow0 + 16 * ph + (n16 & 7);
+          const int cha = (n16 < 8 ? 0 : 32) + 8 * G;
+          const bool cka = cha + 7 < a.Cout && oh < a.OH;
+          const unsigned o1 = (cka && owa < a.OW) ? (unsigned)((oh * a.OW + owa) * a.y_ldc + cha) * 2u : H_OOB;
+          const unsigned o2 = (cka && owa + 8 < a.OW) ? (unsigned)((oh * a.OW + owa + 8) * a.y_ldc + cha) * 2u : H_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(d1, yrs, o1, 0, SAUX);
+          __builtin_amdgcn_raw_buffer_store_b128(d2, yrs, o2, 0, SAUX);
+        }
+#else
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const bool ok = ((valid >> (2 * mm + ph)) & 1) && cok[p];
+          const unsigned off = ok ? (unsigned)(pix[mm][ph] * a.y_ldc + 32 * p + 8 * G) * 2u : H_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(hw[p], yrs, off, 0, SAUX);
+        }
+#endif
+      }
     }
   }
   if (wsigns) *sgp = sbits;
@@ -1197,11 +1239,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       H16C_STAMP(0, c, 1);
-      const int n_aux = (ep.r1 ? 1 : 0) + (ep.r2 ? 1 : 0) + (ep.mask ? 1 : 0);
-      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
-      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
-      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
-      else h16_epilogue16<T, MT, 3, STORE_AUX>(ep, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      const int n_aux = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0) + (a.mask ? 1 : 0);
+      if (n_aux == 0) h16_epilogue16<T, MT, 0, STORE_AUX>(ep, a, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else if (n_aux == 1) h16_epilogue16<T, MT, 1, STORE_AUX>(ep, a, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else if (n_aux == 2) h16_epilogue16<T, MT, 2, STORE_AUX>(ep, a, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
+      else h16_epilogue16<T, MT, 3, STORE_AUX>(ep, a, acc, n, oh0, ow0, wv, lane, tile, lds_signs, c);
       H16C_STAMP(0, c, 2);
       sig_pending = c + 1 < nconv;
     }

@@ -85,11 +85,11 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  // The bias gradient is a plain sum of dy over every pixel -- for the discriminators a difference of nearly equal sums (real minus fake
-  // pass, esrgan.py:578-581: at 32 x 256 x 256 float32 arithmetic of ANY order is 2e-3 ... 1e-2 of the tensor's max away from the float64
-  // result).  It costs two instructions per nine MFMAs to keep it in double all the way: here, through the LDS, and in the partials
-  // ((hi, lo) float pairs, WBatch::bias_lo), so that this path adds nothing to what float32 dy values already carry.
-  double bsum = 0.0;
+  // The bias gradient is a plain sum of dy over every pixel, in float32 here and in double across the pixel-split partials (reduce
+  // kernels).  (Round 4 tried it in double end to end, (hi, lo) partials and all, on the suspicion that this sum was why a discriminator
+  // bias gradient sits 1e-2 from the float64 oracle: it is not -- the sum equals the float64 sum of the same dy to 2e-8 ... 2e-7 either
+  // way, profiles/r04_bias_path_diagnosis.txt -- and the double path cost this kernel 22 spilled registers and 16 % of its time.)
+  float bsum = 0.f;
 
   const int t_begin = p * B.tpb;
   int t_end = t_begin + B.tpb;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
         const int cur = kk & 1;
         if (kk + 1 < KQ) ld_k(cur ^ 1, kk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (do_bias) bsum += (double)av[cur];
+        if (do_bias) bsum += av[cur];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][tap], acc[tap], 0, 0, 0);
@@ -260,16 +260,11 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       }
       __syncthreads();
     }
-    if (ks > 0) {
-      const float hi = (float)bsum;
-      smem[9216 + ((ks - 1) * NL + tl) * 64 + lane] = hi;
-      smem[9216 + 256 + ((ks - 1) * NL + tl) * 64 + lane] = (float)(bsum - (double)hi);
-    }
+    if (ks > 0) smem[9216 + ((ks - 1) * NL + tl) * 64 + lane] = bsum;
     __syncthreads();
     if (ks == 0)
 #pragma unroll
-      for (int q = 1; q < KSP; ++q)
-        bsum += (double)smem[9216 + ((q - 1) * NL + tl) * 64 + lane] + (double)smem[9216 + 256 + ((q - 1) * NL + tl) * 64 + lane];
+      for (int q = 1; q < KSP; ++q) bsum += smem[9216 + ((q - 1) * NL + tl) * 64 + lane];
   }
   // ---- write partial block: part[p][chunk][tap][64 cout][64 cin]
   if (active && ks == 0) {
@@ -283,13 +278,8 @@ __global__ __launch_bounds__(SRK_THREADS, 2) void wgrad_f32_kernel(const WBatch 
       }
   }
   if (do_bias && ks == 0) {
-    const double tot = bsum + __shfl_xor(bsum, 32);
-    const float hi = (float)tot;
-    if (hl == 0) {
-      const size_t at = ((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32;
-      pbias[at] = hi;
-      if (B.bias_lo) (part + B.lo_off)[at] = (float)(tot - (double)hi);
-    }
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    if (hl == 0) pbias[((size_t)p * B.n_chunks + chunk) * 64 + 32 * wa + l32] = tot;
   }
 }
 
@@ -1122,17 +1112,14 @@ int launch(const WBatch& B, float* part, float* pbias, hipStream_t st) {
     SRK_CHECK_LAUNCH();
     return launch_reduce(B, part, pbias, st);
   }
-  WBatch Bd = B;              // the direct kernel keeps its bias sums in double: (hi, lo) partials
-  Bd.bias_lo = 1;
-  Bd.lo_off = ws_lo_off(B);
   if (DYMODE == SRK_IN_PLAIN && ksp == 4)
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 4>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   else if (DYMODE == SRK_IN_PLAIN && ksp == 2)
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, SRK_IN_PLAIN, VEC, 2>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   else
-    hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC, 1>), grid, dim3(SRK_THREADS), 0, st, Bd, part, pbias);
+    hipLaunchKernelGGL((wgrad_f32_kernel<S, DYMODE, VEC, 1>), grid, dim3(SRK_THREADS), 0, st, B, part, pbias);
   SRK_CHECK_LAUNCH();
-  return launch_reduce(Bd, part, pbias, st);
+  return launch_reduce(B, part, pbias, st);
 }
 
 }  // namespace

@@ -406,7 +406,8 @@ def test_full_size_gan_step_batch32_vs_oracle_and_schedule_bit_identity():
         # review suspected the bias summation of the weight-gradient kernel; measured (tools/debug/bias_path.py,
         # profiles/r04_bias_path_diagnosis.txt): every bias gradient the library returns equals the float64 sum of the dy tensor it was
         # GIVEN to 2e-8 ... 2e-7 -- the distance is in dy before the kernel sees it (correlated float32 rounding of the loss gradient,
-        # amplified by the cancellation), not in the sum, and a bias path in double (kept: it is free) did not move it.  So the bar per
+        # amplified by the cancellation), not in the sum, and a bias path in double end to end did not move it (dropped again: it cost the
+        # kernel 16 %; the pixel-split partials are still added in double, which is free).  So the bar per
         # tensor is the reference arithmetic's WORST tensor of the same discriminator, not its luck on the same tensor: 5e-3, or
         # 1.5 x max over the discriminator's tensors of CPU float32's distance (round 3: a flat 2e-2).  All gradients together (L2): 5e-3.
         num = den = 0.0
