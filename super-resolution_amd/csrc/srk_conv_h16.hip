@@ -42,6 +42,19 @@ typedef unsigned h16_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef H16_EPI_FULL_LINES
 #define H16_EPI_FULL_LINES 0
 #endif
+// H16_EPI_SIGNS_PK: 1 (default) = the epilogue's sign bits from packed 16-bit integer min / max on the halves that are stored, 0 = round 3's
+// convert back + compare per element.
+#ifndef H16_EPI_SIGNS_PK
+#define H16_EPI_SIGNS_PK 1
+#endif
+// H16_EPI_EXP (diagnostic variant builds only, results WRONG): 1 = the 16x16x32 epilogue's stores dropped, 2 = no sign-bit / mask / LeakyReLU work
+// H16_EPI_MASK_ARITH: 1 = the LeakyReLU' factors of the sign-bit mask by bit arithmetic, 0 = compare + select per element
+#ifndef H16_EPI_MASK_ARITH
+#define H16_EPI_MASK_ARITH 0
+#endif
+#ifndef H16_EPI_EXP
+#define H16_EPI_EXP 0
+#endif
 
 namespace {
 
@@ -311,7 +324,7 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, const srk_c
   // values live across the stage loops, where every register is taken, and come back from scratch in the middle of the epilogue)
   asm volatile("" : "+v"(lane));
   h16_u32x4 sbits = {0u, 0u, 0u, 0u};
-  const bool wsigns = (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = (a.flags & SRK_CONV_MASK_SIGNS) != 0;
+  const bool wsigns = !(H16_EPI_EXP & 2) && (a.flags & SRK_CONV_WRITE_SIGNS) != 0, msigns = !(H16_EPI_EXP & 2) && (a.flags & SRK_CONV_MASK_SIGNS) != 0;
   h16_u32x4* const sgp = reinterpret_cast<h16_u32x4*>(a.signs) + ((long)tile * 4 + wv) * 64 + lane;
   if (msigns) sbits = lsig[wv * 64 + lane];          // (a loader wave fetched the workgroup's 4 KB of bits during the conv: no global round trip here)
   constexpr int TB = NS <= 1 ? MT : (NS == 2 ? (MT >= 2 ? MT / 2 : 1) : 1);      // rows per batch (loads ahead of stores)
@@ -321,7 +334,7 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, const srk_c
   for (int p = 0; p < 2; ++p) cok[p] = 32 * p + 8 * G + 7 < a.Cout;
   // (the residual / mask views of the few convs that have any -- a block's last conv; data gradients without sign bits -- are read here)
   const bool has_r1 = NS > 0 && ax.r1 != nullptr, has_r2 = NS > 0 && ax.r2 != nullptr;
-  const float alpha = a.alpha, beta1 = ax.beta1, beta2 = ax.beta2, slope = a.slope, mask_slope = a.mask_slope;
+  const float alpha = a.alpha, beta1 = ax.beta1, beta2 = ax.beta2, slope = (H16_EPI_EXP & 2) ? 1.f : a.slope, mask_slope = a.mask_slope;
   const long img_px = (long)a.OH * a.OW;
   auto rsrc16 = [&](const float* p, int ldc, int coff) {
     const T* q = reinterpret_cast<const T*>(p) + (long)n * img_px * ldc + coff;
@@ -413,23 +426,52 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, const srk_c
             }
           }
           if (msigns) {
+#if H16_EPI_MASK_ARITH
+            // factor = bit ? 1 : mask_slope as a bit select under the sign-extended bit (v_bfe_i32 + v_bitop3 per element, the products in
+            // packed pairs): no compare, no condition register, none of the wait states behind them
+            const unsigned one = 0x3f800000u, sl = __builtin_bit_cast(unsigned, mask_slope);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const unsigned mk = (unsigned)((int)(sbits[it >> 2] << (31 - 8 * (it & 3) - e)) >> 31);
+              o[e] *= __builtin_bit_cast(float, (mk & one) | (~mk & sl));
+            }
+#else
             const unsigned byte = sbits[it >> 2] >> (8 * (it & 3));
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = ((byte >> e) & 1u) ? o[e] : o[e] * mask_slope;
+#endif
           }
           const bool ok = ((valid >> (2 * mm + ph)) & 1) && cok[p];
           h16_f32x8 ov;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = o[e];
           const v8 hv = __builtin_convertvector(ov, v8);
-          if (wsigns) {                                    // the sign of what is STORED
+          hw[p] = __builtin_bit_cast(h16_u32x4, hv);
+          if (wsigns) {
+            // The sign of what is STORED (a value that rounds to zero counts as not positive), on the packed halves themselves: a
+            // 16-bit float is > 0 exactly when its bits, read as a signed 16-bit integer, are (fp16 and bf16 alike; -0 = 0x8000 is
+            // negative, NaNs do not occur), so max(min(h, 1), 0) leaves 1 / 0 in bit 0 of each half -- two packed integer instructions
+            // per dword instead of convert back + compare + select per ELEMENT (the round-3 form: ~40 vector instructions per item,
+            // with a wait state behind every compare; one wave per SIMD pays each of them in full).
+            // (inline assembly: the compiler lowers the packed min / max of <2 x i16> to a compare + select per half.)
+#if H16_EPI_SIGNS_PK
+            unsigned g = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              unsigned b2;
+              asm("v_pk_min_i16 %0, %1, %2" : "=v"(b2) : "v"(hw[p][k]), "v"(0x00010001u));
+              asm("v_pk_max_i16 %0, %1, 0" : "=v"(b2) : "v"(b2));
+              g |= b2 << (2 * k);                            // element 2 k at bit 2 k, element 2 k + 1 at bit 16 + 2 k
+            }
+            const unsigned byte = (g & 0x55u) | ((g >> 15) & 0xaau);
+#else
             const h16_f32x8 back = __builtin_convertvector(hv, h16_f32x8);
             unsigned byte = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) byte |= (back[e] > 0.f ? 1u : 0u) << e;
+#endif
             sbits[it >> 2] |= (ok ? byte : 0u) << (8 * (it & 3));
           }
-          hw[p] = __builtin_bit_cast(h16_u32x4, hv);
         }
         // FULL-LINE STORES.  The lane (n16, G) holds channels 8 G .. of half p = 0 and 32 + 8 G .. of half p = 1 of pixel n16: stored as they
         // are, an instruction writes 64 of a pixel's 128 bytes.  Here the two halves of a pixel first meet in ONE instruction: lanes
@@ -460,7 +502,7 @@ __device__ __forceinline__ void h16_epilogue16(const h16_epi_pre& a, const srk_c
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const bool ok = ((valid >> (2 * mm + ph)) & 1) && cok[p];
-          const unsigned off = ok ? (unsigned)(pix[mm][ph] * a.y_ldc + 32 * p + 8 * G) * 2u : H_OOB;
+          const unsigned off = (ok && !(H16_EPI_EXP & 1)) ? (unsigned)(pix[mm][ph] * a.y_ldc + 32 * p + 8 * G) * 2u : H_OOB;
           __builtin_amdgcn_raw_buffer_store_b128(hw[p], yrs, off, 0, SAUX);
         }
 #endif

@@ -90,7 +90,7 @@ if __name__ == "__main__":
     reps = int(os.environ.get("REPS", 5))
     bad = 0
     TN, THW = int(os.environ.get("N", 32 if fmt == 6 else 8)), int(os.environ.get("HW", 64 if fmt == 6 else 128))
-    for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (TN, THW, THW)):
+    for (N, H, W) in ((1, 16, 32), (1, 40, 70), (2, 48, 96), (3, 33, 31), (TN, THW, THW)) if not os.environ.get("TIMING_ONLY") else ():
         for bw in (False, True):
             r = check(N, H, W, reps if N < 8 else 3 * reps, bw)
             bad += r > {6: 0.0, 7: 4e-3, 8: 3.2e-2}[fmt]          # (16-bit: a few units in the last place of the storage type: 2^-10 / 2^-7)
