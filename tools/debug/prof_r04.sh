@@ -24,8 +24,3 @@ echo traffic-done
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
 echo default-done
 find $out -name "*.csv" | head -30
-for ns in 0 1500 3000; do
-  echo "== w42 N=32 skew $ns ns x 4 groups (protocol v4)" >> $out/skew_w42_v4.txt
-  SRK_W42_CHAIN_SKEW_NS=$ns FMT=6 REPS=1 timeout -k 10 200 python3 tools/debug/chain_check.py 2>&1 | grep "block at" >> $out/skew_w42_v4.txt
-done
-cat $out/skew_w42_v4.txt
