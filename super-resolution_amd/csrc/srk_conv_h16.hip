@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void conv3x3_h16_chain_kernel(const 
     // group holds each i once).  In the X read a group holds pixels {0-3, 12-15} of one k-group and {4-11} of the next, so the four lanes
     // on one value of hp & 3 carry (kg, quad (hp >> 2) & 3) = (k, q), (k + 1, q + 1), (k + 1, q + 2), (k, q + 3): with the one-conv kernels'
     // swizzle, position = kg ^ quad, two of them meet -- every X read took 8 cycles instead of 4 (PMC, first build of this form:
-    // SQ_LDS_BANK_CONFLICT = 29 % of SQ_LDS_IDX_ACTIVE, the LDS busy 74 % of the kernel).  position = kg ^ 2 (quad & 1) is conflict-free for
+    // SQ_LDS_BANK_CONFLICT = 29 % of SQ_LDS_IDX_ACTIVE; now 0.  The kernel's time did not move: the LDS array is busy ~15 % of it).  position = kg ^ 2 (quad & 1) is conflict-free for
     // every alignment of hp (exhaustive check of all XOR swizzles by quad: tools/debug/h16_m16_banks.py); the loader waves stage the image
     // that way for this form.  ph = 1 is ph = 0 plus 1024 bytes (the swizzle repeats every 8 pixels).
     // A stage = 3 shifts s x 6 halo rows ri x 2 pixel halves ph = 36 steps; step (s, ri, ph) feeds the kernel rows r with output row

@@ -11,7 +11,7 @@ echo gan-serial-done
 SRK_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats -d $out/prof_c4_serial -o p --output-format csv -- python3 bench.py --workload c4 --steps 5 --warmup 2 --no-alt --no-cpu-baseline --no-configs > $out/bench_c4_profiled_serial.json 2> $out/prof_c4_serial.err || { tail -5 $out/prof_c4_serial.err; exit 1; }
 echo c4-serial-done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_mfma -o m --output-format csv -- $G > /dev/null 2> $out/pmc_mfma.err || { tail -5 $out/pmc_mfma.err; exit 1; }
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES --kernel-trace -d $out/pmc_sq -o s --output-format csv -- $G > /dev/null 2> $out/pmc_sq.err || { tail -5 $out/pmc_sq.err; exit 1; }
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $out/pmc_sq -o s --output-format csv -- $G > /dev/null 2> $out/pmc_sq.err || { tail -5 $out/pmc_sq.err; exit 1; }
 echo gan-mfma-done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES --kernel-trace -d $out/pmc_mfma_c4 -o m --output-format csv -- $C > /dev/null 2> $out/pmc_mfma_c4.err || { tail -5 $out/pmc_mfma_c4.err; exit 1; }
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $out/pmc_sq_c4 -o s --output-format csv -- $C > /dev/null 2> $out/pmc_sq_c4.err || { tail -5 $out/pmc_sq_c4.err; exit 1; }
@@ -23,4 +23,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pmc_write_c4 -o w --output-for
 echo traffic-done
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
 echo default-done
-find $out -name "*.csv" | head -30
+timeout -k 10 300 python3 tools/debug/soak.py > $out/soak.txt 2>&1 || { tail -20 $out/soak.txt; exit 1; }
+cat $out/soak.txt
