@@ -1215,7 +1215,11 @@ extern "C" int srk_conv3x3_wgrad_kernel_name(const srk_wgrad_args* args, int n, 
     snprintf(buf, len, "wgrad_h16_kernel<%s, %d, %s, 8>", a0.precision == 3 ? "_Float16" : "__bf16", a0.dy_mode, B.h16 == 2 ? "true" : "false");
     return SRK_OK;
   }
-  if (a0.stride == 1 && vec && B.wino == 2) { snprintf(buf, len, "wgrad_f32_wino22_kernel<%d, %s>", a0.dy_mode, srk_wgrad_wino22_rows() ? "true" : "false"); return SRK_OK; }
+  if (a0.stride == 1 && vec && B.wino == 2) {
+    if (srk_wgrad_wino22_rows() == 2) snprintf(buf, len, "wgrad_f32_wino24_kernel<%d>", a0.dy_mode);
+    else snprintf(buf, len, "wgrad_f32_wino22_kernel<%d, %s>", a0.dy_mode, srk_wgrad_wino22_rows() ? "true" : "false");
+    return SRK_OK;
+  }
   if (a0.stride == 1 && vec && B.wino) { snprintf(buf, len, "wgrad_f32_wino_kernel<%d>", a0.dy_mode); return SRK_OK; }
   int ksp = 1;
   if (a0.dy_mode == SRK_IN_PLAIN) {

@@ -33,6 +33,9 @@ constexpr int W22_THREADS = 256;
 #ifndef W22_NPS
 #define W22_NPS 1        // row-owner form: DMA piece pairs per k-step (1: a tile's 20 pieces per wave ride on ten k-steps; 2: on five)
 #endif
+#ifndef W22_DEFAULT_FORM
+#define W22_DEFAULT_FORM 1
+#endif
 #ifndef W22_RG
 #define W22_RG 7         // row-owner form: the MFMA gap of a k-step that holds ALL its vector-ALU work (raw reads: gaps 0-5)
 #endif
@@ -524,25 +527,348 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino22_kernel(const WBa
   W22_STAMP(3);
 }
 
+
+// =========================================================================================================================
+// "wino24" (round 4): the transposed F(2,3) along the image COLUMN (as above) times the transposed F(4,3) along the image ROW: a 2 x 4
+// patch of dy and the 4 x 6 patch of x around it give the nine taps from 24 products instead of 72 -- a THIRD of the direct kernel's
+// MFMAs (wino22: 4/9), the algorithm the F(2x4,3x3) conv kernels run forwards:
+//     U = A_h g A_w^T (4 x 6 from the 2 x 4 dy patch),  V = B_h^T d B_w (4 x 6 from the x patch),  M_pq += U_pq V_pq,  dW = G_h^T M G_w
+//     A_w (6 x 4) = transpose of F(4,3)'s A^T:  u0 = g0, u1 = g0+g1+g2+g3, u2 = g0-g1+g2-g3, u3 = g0+2g1+4g2+8g3, u4 = g0-2g1+4g2-8g3, u5 = g3
+//     B_w^T = F(4,3)'s (4,0,-5,0,1,0 | 0,-4,-4,1,1,0 | 0,4,-4,-1,1,0 | 0,-2,-1,2,1,0 | 0,2,-1,-2,1,0 | 0,4,0,-5,0,1);  G_w = its G (6 x 3)
+// Row-owner form only: wave w owns ROW w of the 4 x 6 positions for the whole 64 x 64 chunk = 6 x 2 x 2 = 24 accumulator tiles (384 registers:
+// 16 tiles in the accumulation registers, 8 in vector registers; the MFMAs are inline assembly with the class spelled out, as in
+// srk_conv_w42.hip; tools/check_w42_hazards.py lints them).  Same tiles (8 x 16 dy pixels + halo), same LDS image, same DMA pieces, same
+// partial-block format as wino22: a tile is 8 k-steps (pairs of horizontally adjacent patches) of 24 MFMAs instead of 16 of 16.
+// Operand transform per k-step: 30 packed instructions + 1 (bias), the pairs being the two cout tiles (U) resp. the two cin tiles (V) --
+// each raw value is read by its own ds_read_b32 into one half of an aligned register pair (LDS reads are free beside fp32 MFMAs).
+// The DMA plan is not held per piece (2 x 20 registers in wino22; here there are none to spare): a dy piece's lane offset is the same for
+// every piece, an x piece's is one of two (pieces that cross the end of an 18-pixel halo row), the piece's part is wave-uniform.
+template <int DYMODE>
+__global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBatch B, float* part, float* pbias) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * W22_TILE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l32 = lane & 31;
+  int p, chunk;
+  {
+    const int id = blockIdx.x, nc = B.n_chunks, pm = B.P & ~7;
+    if (id < pm * nc) { const int s_ = id >> 3; p = (id & 7) + 8 * (s_ / nc); chunk = s_ - (s_ / nc) * nc; }
+    else { const int r_ = id - pm * nc; p = pm + r_ / nc; chunk = r_ - (r_ / nc) * nc; }
+  }
+  const int pi = __builtin_amdgcn_readfirstlane(B.c_prob[chunk]);
+  const int cy = __builtin_amdgcn_readfirstlane(B.c_cy[chunk]), cz = __builtin_amdgcn_readfirstlane(B.c_cz[chunk]);
+  const WProb& a = B.prob[pi];
+  const int cin0 = cy * 64, cout0 = cz * 64;
+  const int Cps = a.Cout >> 2;
+
+  f32x16 acc[24];
+#pragma unroll
+  for (int t = 0; t < 24; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto mfma = [&](int t, float va, float vb) {       // t is a constant after unrolling
+    if (t < 16) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(va), "v"(vb));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(va), "v"(vb));
+  };
+
+  const int t_begin = p * B.tpb;
+  int t_end = t_begin + B.tpb;
+  if (t_end > B.total_tiles) t_end = B.total_tiles;
+
+  const long x_img = (long)B.H * B.W * a.x_ldc;
+  const long dy_img = (long)B.OH * B.OW * a.dy_ldc * (DYMODE == SRK_IN_UNSHUFFLE ? 4 : 1);
+  const long xb_l = ((long)(B.H * B.W - 1) * a.x_ldc + a.Cin) * 4, db_l = dy_img * 4;
+  const unsigned xbytes = (unsigned)(xb_l > 0x7fffffffL ? 0x7fffffffL : xb_l);
+  const unsigned dbytes = (unsigned)(db_l > 0x7fffffffL ? 0x7fffffffL : db_l);
+  // ---- DMA plan: piece 4 j + wv of the tile buffer's 80 one-KB slots (4 consecutive pixels x 16 channel quads), j < 8: dy row j,
+  // pixels 4 wv .. 4 wv + 3; j >= 8: halo pixels 4 k .. 4 k + 3, k = 4 (j - 8) + wv (k >= 45: padding).
+  constexpr int NPW = 20;
+  const int c4 = lane & 15, lp = lane >> 4;
+  const int co = cout0 + 4 * c4, ci = cin0 + 4 * c4;
+  int dyc, dyij = 0;
+  if (DYMODE == SRK_IN_UNSHUFFLE) { dyij = co / Cps; dyc = co - dyij * Cps; } else { dyc = co; }
+  const bool co_ok = co < a.Cout, ci_ok = ci < a.Cin;
+  const int cdy = 4 * wv + lp;                                     // this lane's dy column inside the tile, the same in every dy piece
+  unsigned laneDy = DYMODE == SRK_IN_UNSHUFFLE ? (unsigned)((((dyij >> 1) * (2 * B.OW) + 2 * cdy + (dyij & 1)) * a.dy_ldc + dyc) * 4)
+                                                     : (unsigned)((cdy * a.dy_ldc + dyc) * 4);
+  const unsigned dyRow = (unsigned)((DYMODE == SRK_IN_UNSHUFFLE ? 4 * B.OW : B.OW) * a.dy_ldc * 4);
+  int lpd = co_ok ? cdy : -(1 << 20);
+  // halo pixel hp = 4 k + lp = 18 hy + hx.  With 4 k = 18 a + b (b even, <= 16) only b = 16 lets lanes lp >= 2 run into the next row:
+  // their offset is the plain one + (W - 18) pixels, their column the plain one - 18
+  unsigned laneX = (unsigned)((lp * a.x_ldc + ci) * 4);
+  unsigned laneXw = laneX + (lp >= 2 ? (unsigned)((B.W - W22_IW) * a.x_ldc * 4) : 0u);
+  int lpx = ci_ok ? lp : -(1 << 20);
+  int lpxw = ci_ok ? (lp >= 2 ? lp - W22_IW : lp) : -(1 << 20);
+  struct TileCtx { int ow0; unsigned org_dy, org_x; __amdgpu_buffer_rsrc_t xr, dr; };
+  struct TilePos { int tx, ty, n; };
+  auto tile_pos = [&](int tile) {
+    TilePos q;
+    int tt = tile;
+    q.tx = tt % B.tilesW; tt /= B.tilesW;
+    q.ty = tt % B.tilesH; q.n = tt / B.tilesH;
+    return q;
+  };
+  auto pos_step = [&](TilePos& q, bool go) {
+    int tx = q.tx + 1, ty = q.ty, n = q.n;
+    const bool wx = tx == B.tilesW;
+    tx = wx ? 0 : tx; ty += wx ? 1 : 0;
+    const bool wy = ty == B.tilesH;
+    ty = wy ? 0 : ty; n += wy ? 1 : 0;
+    q.tx = go ? tx : q.tx; q.ty = go ? ty : q.ty; q.n = go ? n : q.n;
+  };
+  auto ctx_offsets = [&](const TilePos& q, TileCtx& c) {
+    const int oh0 = q.ty * W22_TH;
+    c.ow0 = q.tx * WTW;
+    c.org_dy = (unsigned)((DYMODE == SRK_IN_UNSHUFFLE ? (2 * oh0 * 2 * B.OW + 2 * c.ow0) : (oh0 * B.OW + c.ow0)) * a.dy_ldc * 4);
+    c.org_x = (unsigned)((oh0 * B.W + c.ow0) * a.x_ldc * 4);
+  };
+  auto ctx_rsrcs = [&](const TilePos& q, TileCtx& c) {
+    c.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + q.n * x_img + a.x_coff), 0, xbytes, 0x00020000);
+    c.dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + q.n * dy_img + a.dy_coff), 0, dbytes, 0x00020000);
+  };
+  // piece j of this wave (j: compile-time after unrolling).  Everything about the piece itself is wave-uniform scalar arithmetic; the offset
+  // goes out through the VECTOR offset (the hardware's range check, which drops the rows above / below the image, does not cover the scalar one)
+  auto piece = [&](const TileCtx& c, int b, int j, bool live) {
+    float* dst = smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256;
+    if (j < 8) {
+      const unsigned so = c.org_dy + (unsigned)j * dyRow;
+      const int ow = live ? c.ow0 : (1 << 28);
+      const bool ok = (unsigned)(lpd + ow) < (unsigned)B.OW;
+      wdma16(c.dr, dst, ok ? laneDy + so : W_OOB);
+    } else {
+      const int k = 4 * (j - 8) + wv, hp0 = 4 * k, ar = hp0 / W22_IW, bq = hp0 - W22_IW * ar;
+      const bool isw = bq == 16;
+      const unsigned so = c.org_x + (unsigned)(((ar - 1) * B.W + bq - 1) * a.x_ldc * 4);
+      const int ow = (live && k < W22_NHP / 4) ? c.ow0 : (1 << 28);
+      const int lc = isw ? lpxw : lpx;
+      const unsigned lo = isw ? laneXw : laneX;
+      const bool ok = (unsigned)(lc + bq - 1 + ow) < (unsigned)B.W;
+      wdma16(c.xr, dst, ok ? lo + so : W_OOB);
+    }
+  };
+
+  //   B_h^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3);  A_h rows: (g0, g0 + g1, g0 - g1, g1)   -- one combination of two raw rows per wave
+  const int xra = wv == 0 ? 0 : (wv == 2 ? 2 : 1);
+  const int xrb = wv == 0 ? 2 : (wv == 1 ? 2 : (wv == 2 ? 1 : 3));
+  const float xs = wv == 1 ? 1.f : -1.f;
+  const int dra = wv == 3 ? 1 : 0;
+  const int drb = (wv == 1 || wv == 2) ? 1 : dra;
+  const float dsc = wv == 1 ? 1.f : (wv == 2 ? -1.f : 0.f);
+  // LDS BYTE addresses of (row ra / rb of the patch, column 4 hl [+ 3 for the second x pointer], channel l32) of the k-step whose raw values are
+  // read next.  They RUN with the k-steps (advanced in the transform gap, by constants) and are opaque to the compiler: every read is
+  // pointer + a small immediate -- derived from one base per buffer, the step offsets exceed what a ds_read2_b32 can address and every
+  // group of reads got a v_add of its own, i.e. a vector-ALU gap (14 cycles beside fp32 MFMAs) per group.
+  unsigned pgA = (unsigned)(((4 * hl) * 64 + l32 + dra * 16 * 64) * 4), pgB = (unsigned)(((4 * hl) * 64 + l32 + drb * 16 * 64) * 4);
+  unsigned pdA = (unsigned)((W22_TP * 64 + (4 * hl) * 64 + l32 + xra * W22_IW * 64) * 4), pdB = (unsigned)((W22_TP * 64 + (4 * hl) * 64 + l32 + xrb * W22_IW * 64) * 4);
+  unsigned pdA3 = pdA + 3 * 64 * 4, pdB3 = pdB + 3 * 64 * 4;
+  const f32x2 xs2 = {xs, xs}, dsc2 = {dsc, dsc};
+  f32x2 bs2 = {0.f, 0.f};
+  f32x2 U0[6], V0[6], U1[6], V1[6];
+  f32x2 gA[4], gB[4], dA[6], dB[6];          // raw pairs: [pixel j][cout tile m] resp. [pixel j][cin tile n]
+  const char* sm = reinterpret_cast<const char*>(smem);
+  auto ldsf = [&](unsigned addr, int off_floats) { return *reinterpret_cast<const float*>(sm + addr + 4 * off_floats); };
+  auto rd_g = [&](bool second) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) (second ? gB : gA)[j][m] = ldsf(second ? pgB : pgA, 64 * j + 32 * m);
+  };
+  auto rd_d = [&](int j0, bool second) {
+#pragma unroll
+    for (int j = j0; j < j0 + 3; ++j)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) (second ? dB : dA)[j][n] = ldsf(j0 ? (second ? pdB3 : pdA3) : (second ? pdB : pdA), 64 * (j - j0) + 32 * n);
+  };
+  // the pointers move on to the k-step behind the one just read: dg / dx BYTES (compile-time except across the tile boundary)
+  auto advance = [&](int dg, int dx) {
+    pgA += dg; pgB += dg; pdA += dx; pdB += dx; pdA3 += dx; pdB3 += dx;
+    asm volatile("" : "+v"(pgA), "+v"(pgB), "+v"(pdA), "+v"(pdB), "+v"(pdA3), "+v"(pdB3));
+  };
+#define W24_PKFMA(r, k, x, y) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(k), "v"(x), "v"(y))
+#define W24_PKADD(r, x, y) asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y))
+#define W24_PKSUB(r, x, y) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y))
+  // U (both cout tiles): row pass t_j = gA_j + s gB_j, then A_w: 12 packed; `real` = {1, 1} / {0, 0}: the patch sum (row g0 + g1, position 1)
+  // counts towards the bias unless the operands are formed behind the last tile
+  auto xf_u = [&](f32x2 (&U)[6], f32x2 real2) {
+    const f32x2 k4 = {4.f, 4.f}, k2 = {2.f, 2.f}, kM2 = {-2.f, -2.f};
+    f32x2 t[4], s02, s13, aa, b4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W24_PKFMA(t[j], dsc2, gB[j], gA[j]);
+    W24_PKADD(s02, t[0], t[2]); W24_PKADD(s13, t[1], t[3]);
+    W24_PKFMA(aa, k4, t[2], t[0]); W24_PKFMA(b4, k4, t[3], t[1]);
+    W24_PKADD(U[1], s02, s13); W24_PKSUB(U[2], s02, s13);
+    W24_PKFMA(U[3], k2, b4, aa); W24_PKFMA(U[4], kM2, b4, aa);
+    U[0] = t[0]; U[5] = t[3];
+    W24_PKFMA(bs2, real2, U[1], bs2);
+  };
+  // V (both cin tiles): row pass d_j = dA_j + s dB_j, then B_w^T in 12: 18 packed
+  auto xf_v = [&](f32x2 (&V)[6]) {
+    const f32x2 kM4 = {-4.f, -4.f}, k4 = {4.f, 4.f}, kM5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, kM2 = {-2.f, -2.f};
+    f32x2 d[6], t1, t2, t3, t4, u0, u5;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) W24_PKFMA(d[j], xs2, dB[j], dA[j]);
+    W24_PKFMA(t1, kM4, d[2], d[4]); W24_PKFMA(t2, kM4, d[1], d[3]);
+    W24_PKSUB(t3, d[4], d[2]); W24_PKSUB(t4, d[3], d[1]);
+    W24_PKFMA(u0, kM5, d[2], d[4]); W24_PKFMA(V[0], k4, d[0], u0);
+    W24_PKADD(V[1], t1, t2); W24_PKSUB(V[2], t1, t2);
+    W24_PKFMA(V[3], k2, t4, t3); W24_PKFMA(V[4], kM2, t4, t3);
+    W24_PKFMA(u5, kM5, d[3], d[5]); W24_PKFMA(V[5], k4, d[1], u5);
+  };
+  // One k-step = 24 MFMAs on (U, V): accumulator tile i = 4 q + 2 m + n.  In their shadow, by hand (one sched_barrier per MFMA): gaps 0-5 the
+  // raw reads of the NEXT step (buffer nb, step nk), gap W24_RG its whole transform into (UN, VN) and the DMA pieces dj0 .. dj0 + djn - 1 of
+  // the tile dc into buffer db -- ONE vector-ALU gap per k-step (a gap that holds any costs 14 cycles on top of 4 per instruction).
+  constexpr int W24_RG = 8;
+  constexpr int W24_DG = 2 * 16 * 64 * 4, W24_DX = 2 * W22_IW * 64 * 4;          // one patch row down (bytes)
+  constexpr int W24_DG3 = (8 * 64 - 3 * 2 * 16 * 64) * 4, W24_DX3 = (8 * 64 - 3 * 2 * W22_IW * 64) * 4;      // patch row 3 -> row 0 of the next column pair
+  constexpr int W24_G7 = (6 * 16 + 8) * 64 * 4, W24_X7 = (6 * W22_IW + 8) * 64 * 4;            // k-step 7 -> k-step 0 (of the other buffer: +- the buffer size)
+  TilePos pos2;
+  TileCtx c2;
+  // dg / dx: how far the read pointers move behind this step's reads (to the k-step the NEXT call reads)
+  auto kstep = [&](const f32x2 (&U)[6], const f32x2 (&V)[6], f32x2 (&UN)[6], f32x2 (&VN)[6], int dg, int dx,
+                   const TileCtx& dc, int db, int dj0, int djn, bool dlive, f32x2 real2, int mk = 0, bool mk_go = false) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      mfma(i, U[i >> 2][(i >> 1) & 1], V[i >> 2][i & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) rd_g(false);
+      if (i == 1) rd_g(true);
+      if (i == 2) rd_d(0, false);
+      if (i == 3) rd_d(3, false);
+      if (i == 4) rd_d(0, true);
+      if (i == 5) rd_d(3, true);
+      if (mk == 1 && i == 6) { pos_step(pos2, mk_go); ctx_offsets(pos2, c2); ctx_rsrcs(pos2, c2); }
+      if (i == W24_RG) {
+        xf_u(UN, real2);
+        xf_v(VN);
+        advance(dg, dx);
+        if (djn > 0) {
+          // (the lane parts of the piece offsets pass through here so that the pieces' vector-ALU work stays in THIS gap)
+          asm volatile("" : "+v"(laneDy), "+v"(lpd), "+v"(laneX), "+v"(laneXw), "+v"(lpx), "+v"(lpxw));
+#pragma unroll
+          for (int u = 0; u < djn; ++u) piece(dc, db, dj0 + u, dlive);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const f32x2 one2 = {1.f, 1.f};
+  TileCtx cn;
+  if (t_begin < t_end) {
+    pos2 = tile_pos(t_begin);
+    TileCtx c0;
+    ctx_offsets(pos2, c0); ctx_rsrcs(pos2, c0);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) piece(c0, 0, j, true);
+    pos_step(pos2, t_begin + 1 < t_end);
+    ctx_offsets(pos2, cn); ctx_rsrcs(pos2, cn);
+    c2 = cn;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+  __syncthreads();
+  if (t_begin < t_end) {
+    if (t_begin + 1 < t_end) { piece(cn, 1, 0, true); piece(cn, 1, 1, true); }   // (the state every tile starts in: pieces 0, 1 of the next one issued)
+    rd_g(false); rd_g(true);
+    rd_d(0, false); rd_d(3, false); rd_d(0, true); rd_d(3, true);
+    xf_u(U0, one2);
+    xf_v(V0);
+    advance(W24_DG, W24_DX);                                       // -> k-step 1 of buffer 0
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 4");                                        // (VALU results two wait states ahead of the first MFMA that reads them)
+  int b = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    // tile sits in buffer b; tile + 1 is in flight into b ^ 1: pieces 0, 1 went out on the previous tile's last step, 2 .. 19 go out on this
+    // tile's steps 0 .. 3 (five, five, four, four), which leaves steps 4 .. 6 for them to land; tile + 2's pieces 0, 1 ride on the last step,
+    // behind the barrier that releases buffer b
+    const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
+    const int bnp = b ^ 1;
+    const int flip = (b ? -1 : 1) * W22_TILE_FLOATS * 4;            // to the other buffer (bytes)
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 2, 5, more1, one2);            // runs step 0, reads step 1
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 7, 5, more1, one2);            // reads step 2
+    kstep(U0, V0, U1, V1, W24_DG3, W24_DX3, cn, bnp, 12, 4, more1, one2);         // reads step 3
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 16, 4, more1, one2);           // reads step 4
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 0, 0, false, one2, 1, more2);  // reads step 5
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 0, 0, false, one2);            // reads step 6
+    kstep(U0, V0, U1, V1, flip - W24_G7, flip - W24_X7, cn, bnp, 0, 0, false, one2);      // runs step 6, reads step 7; then on to step 0 of tile + 1
+    __builtin_amdgcn_s_waitcnt(0x0070);                            // every piece of tile + 1 has landed (no other VMEM in flight)
+    __builtin_amdgcn_s_barrier();
+    const f32x2 real2 = {more1 ? 1.f : 0.f, more1 ? 1.f : 0.f};
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, c2, b, 0, 2, more2, real2);             // runs step 7: pieces 0, 1 of tile + 2; first operands of tile + 1
+    cn = c2;
+    b ^= 1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+
+  // G_h^T M G_w: the column pass (over the six q) inside the wave, the row pass (over the four waves) through the LDS, one cout tile per
+  // round, exactly as in the wino22 row-owner form
+  float* dst = part + ((size_t)p * B.n_chunks + chunk) * CHUNK_FLOATS;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (m) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float m0 = acc[2 * m + n][e], m1 = acc[4 + 2 * m + n][e], m2 = acc[8 + 2 * m + n][e], m3 = acc[12 + 2 * m + n][e],
+                    m4 = acc[16 + 2 * m + n][e], m5 = acc[20 + 2 * m + n][e];
+        const float s12 = m1 + m2, s34 = m3 + m4;
+        float* o = smem + ((wv * 2 + n) * 16 + e) * 192 + lane;
+        o[0] = 0.25f * m0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        o[64] = (1.f / 6.f) * (m2 - m1) + (1.f / 12.f) * (m3 - m4);
+        o[128] = (1.f / 6.f) * (s34 - s12) + m5;
+      }
+    __syncthreads();
+    const int n = wv & 1;
+    const bool tile_ok = (cout0 + 32 * m < a.Cout) && (cin0 + 32 * n < a.Cin);
+    if (tile_ok) {
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        const int e = 8 * (wv >> 1) + e8;
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * hl;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          const float* q = smem + (n * 16 + e) * 192 + sx * 64 + lane;
+          const float T0 = q[0], T1 = q[2 * 16 * 192], T2 = q[4 * 16 * 192], T3 = q[6 * 16 * 192];
+          const float hs = 0.5f * (T1 + T2);
+          dst[((sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = T0 + hs;
+          dst[((3 + sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = 0.5f * (T1 - T2);
+          dst[((6 + sx) * 64 + 32 * m + i) * 64 + 32 * n + l32] = hs - T3;
+        }
+      }
+    }
+  }
+  if (a.db != nullptr && cy == 0 && wv == 1) {
+    const float t0 = bs2[0] + __shfl_xor(bs2[0], 32), t1 = bs2[1] + __shfl_xor(bs2[1], 32);
+    float* pb = pbias + ((size_t)p * B.n_chunks + chunk) * 64 + l32;
+    if (hl == 0 && cout0 < a.Cout) pb[0] = t0;
+    if (hl == 0 && cout0 + 32 < a.Cout) pb[32] = t1;
+  }
+}
+
 }  // namespace
 
-// Which form of the kernel is launched: 1 (default) the row-owner form, 0 the tile-owner form (every wave forms all 16 positions of
-// its own 32 x 32 tile).  SRK_WGRAD_W22_FORM / srk_debug_set_wgrad_w22_form (A/B measurements, tests).
+// Which form of the kernel is launched: 2 = wino24, the F(2,3) x F(4,3) kernel above (a third of the direct kernel's MFMAs); 1 the row-owner
+// form of wino22 (4/9); 0 its tile-owner form (every wave forms all 16 positions of its own 32 x 32 tile).  SRK_WGRAD_W22_FORM /
+// srk_debug_set_wgrad_w22_form (A/B measurements, tests).
 static int g_w22_rows = -1;
 int srk_wgrad_wino22_rows() {
-  if (g_w22_rows < 0) { const char* e = getenv("SRK_WGRAD_W22_FORM"); g_w22_rows = e ? (atoi(e) != 0) : 1; }
+  if (g_w22_rows < 0) { const char* e = getenv("SRK_WGRAD_W22_FORM"); g_w22_rows = e ? atoi(e) : W22_DEFAULT_FORM; if (g_w22_rows < 0 || g_w22_rows > 2) g_w22_rows = W22_DEFAULT_FORM; }
   return g_w22_rows;
 }
-extern "C" int srk_debug_set_wgrad_w22_form(int rows) { g_w22_rows = rows < 0 ? -1 : (rows != 0); return SRK_OK; }
+extern "C" int srk_debug_set_wgrad_w22_form(int rows) { g_w22_rows = rows < 0 ? -1 : (rows > 2 ? 2 : rows); return SRK_OK; }
 
 int srk_launch_wgrad_wino22(const WBatch& B, float* part, float* pbias, hipStream_t st) {
   const int rows = srk_wgrad_wino22_rows();
   const dim3 grid(B.P * B.n_chunks), blk(W22_THREADS);
   if (B.dy_mode == SRK_IN_UNSHUFFLE) {
-    if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE, true>), grid, blk, 0, st, B, part, pbias);
+    if (rows == 2) hipLaunchKernelGGL((wgrad_f32_wino24_kernel<SRK_IN_UNSHUFFLE>), grid, blk, 0, st, B, part, pbias);
+    else if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE, true>), grid, blk, 0, st, B, part, pbias);
     else hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_UNSHUFFLE, false>), grid, blk, 0, st, B, part, pbias);
   } else {
-    if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN, true>), grid, blk, 0, st, B, part, pbias);
+    if (rows == 2) hipLaunchKernelGGL((wgrad_f32_wino24_kernel<SRK_IN_PLAIN>), grid, blk, 0, st, B, part, pbias);
+    else if (rows) hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN, true>), grid, blk, 0, st, B, part, pbias);
     else hipLaunchKernelGGL((wgrad_f32_wino22_kernel<SRK_IN_PLAIN, false>), grid, blk, 0, st, B, part, pbias);
   }
   SRK_CHECK_LAUNCH();

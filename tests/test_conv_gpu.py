@@ -181,8 +181,8 @@ def test_conv_wgrad(U, ci, co, h, w, stride, n):
 
 @pytest.mark.parametrize("ci,co,h,w,n", [(64, 64, 15, 17, 2), (320, 64, 64, 64, 2), (96, 64, 33, 3, 1), (64, 192, 1, 1, 3), (128, 128, 7, 9, 1)])
 def test_conv_wgrad_wino22_forms(U, ci, co, h, w, n):
-    """Both forms of the 2-D Winograd weight-gradient kernel (row-owner: the default; tile-owner) against the oracle, and against
-    each other to rounding (they add the same products, the transforms in a different order)."""
+    """The forms of the 2-D Winograd weight-gradient kernel (1: wino22 row-owner, 0: wino22 tile-owner, 2: wino24 = F(2,3) x F(4,3)) against
+    the oracle; the two wino22 forms against each other to rounding (they add the same products, the transforms in a different order)."""
     L = U.L
     x = _rand((n, ci, h, w), 31)
     wt = _rand((co, ci, 3, 3), 32, 0.05).requires_grad_(True)
@@ -192,7 +192,7 @@ def test_conv_wgrad_wino22_forms(U, ci, co, h, w, n):
     y.backward(dy)
     got = []
     try:
-        for form in (1, 0):
+        for form in (1, 0, 2):
             L.lib().srk_debug_set_wgrad_w22_form(form)
             dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
             db = torch.full((co,), float("nan"), device="cuda")

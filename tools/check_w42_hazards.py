@@ -49,8 +49,8 @@ def disassemble(obj):
 
 def check_w22():
     """srk_wgrad_w22.hip, row-owner form: its MFMAs are builtins (the compiler sees them), but its packed operand transform is inline
-    assembly, whose results the hazard recogniser cannot classify.  Same rule as 1.: no v_mfma of the wino22 kernels may read a register
-    that one of the two preceding instructions wrote."""
+    assembly, whose results the hazard recogniser cannot classify; the wino24 kernel's MFMAs are inline assembly as well.  Same rule as 1.:
+    no v_mfma of these kernels may read a register that one of the two preceding instructions wrote."""
     obj = os.path.join(ROOT, "super-resolution_amd", "csrc", "build", "srk_wgrad_w22.o")
     if not os.path.exists(obj):
         sys.stderr.write("%s not found: build the library first\n" % obj)
@@ -63,7 +63,7 @@ def check_w22():
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
-            inside, prev = "wino22_kernel" in m.group(1), []
+            inside, prev = ("wino22_kernel" in m.group(1) or "wino24_kernel" in m.group(1)), []
             continue
         if not inside:
             continue
@@ -81,11 +81,11 @@ def check_w22():
             for k, (pm, pd) in enumerate(reversed(prev)):
                 if pm.startswith("v_") and not pm.startswith("v_mfma") and (pd & src):
                     bad += 1
-                    print("HAZARD (wino22): %s reads v%s written %d instruction(s) earlier by %s" % (t, sorted(pd & src), k + 1, pm))
+                    print("HAZARD (wino22 / wino24): %s reads v%s written %d instruction(s) earlier by %s" % (t, sorted(pd & src), k + 1, pm))
         waits = int(ops[0]) + 1 if mn == "s_nop" else 0
         dst = regs(ops[0]) if (ops and mn.startswith("v_") and not mn.startswith("v_cmp")) else set()
         prev = [] if waits >= 2 else (prev + [(mn, dst)])[-2:]
-    print("checked %d v_mfma instructions in the wino22 kernels of super-resolution_amd/csrc/build/srk_wgrad_w22.o: %d violation(s)" % (total, bad))
+    print("checked %d v_mfma instructions in the wino22 / wino24 kernels of super-resolution_amd/csrc/build/srk_wgrad_w22.o: %d violation(s)" % (total, bad))
     return 1 if bad or total == 0 else 0
 
 
