@@ -168,6 +168,9 @@ int srk_debug_chain_inject_fault_async(void* stream);     /* the same from the d
  * epilogues' store bursts, measured without effect; test aid: tiles whose neighbours are late, deterministically) */
 int srk_debug_chain_skew(int kind, unsigned ns, unsigned groups);
 int srk_debug_hold_cus(int workgroups, int usec, void* stream);
+/* Test aid: fills the whole LDS of every CU with NaN bit patterns, so that a kernel that lets LDS bytes it never wrote reach a result
+   fails deterministically in the launch that follows. */
+int srk_debug_poison_lds(void* stream);
 
 /* Weight-gradient of the same convolution:
  *   dW[o][c][r][s] = scale * sum_{n,oh,ow} DY[n,oh,ow,o] * X[n, S*oh+r-1, S*ow+s-1, c]

@@ -23,7 +23,7 @@ EXPORTS = [
     "srk_mask_l1_fwd", "srk_mask_l1_bwd", "srk_hitogram_fwd", "srk_hitogram_bwd", "srk_soft_hist_fwd", "srk_soft_hist_bwd",
     "srk_jet_extract", "srk_strerror", "srk_version",
     "srk_chain_recover", "srk_chain_stats", "srk_chain_epoch_plan", "srk_debug_chain_set", "srk_chain_set_wait_us", "srk_debug_chain_inject_fault",
-    "srk_debug_hold_cus", "srk_adam_count_step", "srk_debug_chain_inject_fault_async", "srk_debug_chain_skew",
+    "srk_debug_hold_cus", "srk_debug_poison_lds", "srk_adam_count_step", "srk_debug_chain_inject_fault_async", "srk_debug_chain_skew",
 ]
 ERR_CHAIN_TIMEOUT = -6
 OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD = 0, 1, 2
@@ -169,6 +169,7 @@ def lib():
         L.srk_debug_chain_inject_fault_async.argtypes = [_fp]
         L.srk_debug_chain_skew.argtypes = [C.c_int, C.c_uint, C.c_uint]
         L.srk_debug_hold_cus.argtypes = [C.c_int, C.c_int, _fp]
+        L.srk_debug_poison_lds.argtypes = [_fp]
         L.srk_adam_count_step.argtypes = [_fp, _fp, _fp, _fp]
         # whatever changes which kernel form a launch takes bumps dispatch_gen: callers that cache a dispatch-dependent answer (the engine's
         # sign-bit decisions) key it with the generation
@@ -199,6 +200,11 @@ def chain_recover() -> int:
     if rc < 0:
         check(rc, "srk_chain_recover")
     return rc
+
+
+def poison_lds():
+    """test aid (srk_debug_poison_lds): NaN bit patterns into the whole LDS of every CU, on the current stream"""
+    check(lib().srk_debug_poison_lds(stream_ptr()), "srk_debug_poison_lds")
 
 
 def chain_stats() -> dict:

@@ -239,7 +239,21 @@ __global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks,
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
   if (sink && pad[(threadIdx.x * 7) & 255] == 0xffffffffu) *sink = 1;          // (keeps the LDS allocation alive)
 }
+// Fills the WHOLE LDS of every CU with a NaN bit pattern (the LDS is not cleared between kernels): a kernel that reads LDS bytes it never
+// wrote -- padding slots of a DMA tile buffer, operands formed behind the last tile -- and lets them reach a result shows up as NaN in the next
+// launch instead of passing or failing with whatever the previous kernel left behind.  1024 workgroups of 160 KB: at least one lands on every CU.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink) {
+  __shared__ unsigned all[40960];
+  for (int i = threadIdx.x; i < 40960; i += 256) all[i] = 0x7fc00000u + (unsigned)(i & 0xffff);
+  __syncthreads();
+  if (sink && all[(threadIdx.x * 37) % 40960] == 0u) *sink = 1;               // (keeps the stores alive)
+}
 }  // namespace
+extern "C" int srk_debug_poison_lds(void* stream) {
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (unsigned*)nullptr);
+  SRK_CHECK_LAUNCH();
+  return SRK_OK;
+}
 extern "C" int srk_debug_hold_cus(int workgroups, int usec, void* stream) {
   if (workgroups <= 0 || workgroups > 4096 || usec <= 0 || usec > 5000000) return SRK_ERR_BAD_ARG;
   hipLaunchKernelGGL(hold_cus_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, (unsigned*)nullptr);

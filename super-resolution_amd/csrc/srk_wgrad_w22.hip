@@ -33,8 +33,11 @@ constexpr int W22_THREADS = 256;
 #ifndef W22_NPS
 #define W22_NPS 1        // row-owner form: DMA piece pairs per k-step (1: a tile's 20 pieces per wave ride on ten k-steps; 2: on five)
 #endif
+#ifndef W24_PIECE_PLAN
+#define W24_PIECE_PLAN 0
+#endif
 #ifndef W22_DEFAULT_FORM
-#define W22_DEFAULT_FORM 1
+#define W22_DEFAULT_FORM 2
 #endif
 #ifndef W22_RG
 #define W22_RG 7         // row-owner form: the MFMA gap of a k-step that holds ALL its vector-ALU work (raw reads: gaps 0-5)
@@ -628,24 +631,30 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
   };
   // piece j of this wave (j: compile-time after unrolling).  Everything about the piece itself is wave-uniform scalar arithmetic; the offset
   // goes out through the VECTOR offset (the hardware's range check, which drops the rows above / below the image, does not cover the scalar one)
-  auto piece = [&](const TileCtx& c, int b, int j, bool live) {
-    float* dst = smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256;
+  // piece_off: the vector-ALU half of a piece (its per-lane offset, out of range where the lane has nothing to fetch); piece_go: the DMA
+  // instruction itself.  Apart in the k-step: the offsets of a step's pieces are formed in its ONE vector-ALU gap, the instructions go out one
+  // per MFMA gap behind it -- back to back they queue in the address unit (measured on the conv kernel: five in a row ~180 cycles each; here:
+  // 45 us of a 480 us launch with all of a step's pieces in one gap).
+  auto piece_off = [&](const TileCtx& c, int j, bool live) -> unsigned {
     if (j < 8) {
       const unsigned so = c.org_dy + (unsigned)j * dyRow;
       const int ow = live ? c.ow0 : (1 << 28);
       const bool ok = (unsigned)(lpd + ow) < (unsigned)B.OW;
-      wdma16(c.dr, dst, ok ? laneDy + so : W_OOB);
-    } else {
-      const int k = 4 * (j - 8) + wv, hp0 = 4 * k, ar = hp0 / W22_IW, bq = hp0 - W22_IW * ar;
-      const bool isw = bq == 16;
-      const unsigned so = c.org_x + (unsigned)(((ar - 1) * B.W + bq - 1) * a.x_ldc * 4);
-      const int ow = (live && k < W22_NHP / 4) ? c.ow0 : (1 << 28);
-      const int lc = isw ? lpxw : lpx;
-      const unsigned lo = isw ? laneXw : laneX;
-      const bool ok = (unsigned)(lc + bq - 1 + ow) < (unsigned)B.W;
-      wdma16(c.xr, dst, ok ? lo + so : W_OOB);
+      return ok ? laneDy + so : W_OOB;
     }
+    const int k = 4 * (j - 8) + wv, hp0 = 4 * k, ar = hp0 / W22_IW, bq = hp0 - W22_IW * ar;
+    const bool isw = bq == 16;
+    const unsigned so = c.org_x + (unsigned)(((ar - 1) * B.W + bq - 1) * a.x_ldc * 4);
+    const int ow = (live && k < W22_NHP / 4) ? c.ow0 : (1 << 28);
+    const int lc = isw ? lpxw : lpx;
+    const unsigned lo = isw ? laneXw : laneX;
+    const bool ok = (unsigned)(lc + bq - 1 + ow) < (unsigned)B.W;
+    return ok ? lo + so : W_OOB;
   };
+  auto piece_go = [&](const TileCtx& c, int b, int j, unsigned voff) {
+    wdma16(j < 8 ? c.dr : c.xr, smem + b * W22_TILE_FLOATS + (4 * j + wv) * 256, voff);
+  };
+  auto piece = [&](const TileCtx& c, int b, int j, bool live) { piece_go(c, b, j, piece_off(c, j, live)); };
 
   //   B_h^T rows: (d0 - d2, d1 + d2, d2 - d1, d1 - d3);  A_h rows: (g0, g0 + g1, g0 - g1, g1)   -- one combination of two raw rows per wave
   const int xra = wv == 0 ? 0 : (wv == 2 ? 2 : 1);
@@ -687,9 +696,9 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
 #define W24_PKFMA(r, k, x, y) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(k), "v"(x), "v"(y))
 #define W24_PKADD(r, x, y) asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y))
 #define W24_PKSUB(r, x, y) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y))
-  // U (both cout tiles): row pass t_j = gA_j + s gB_j, then A_w: 12 packed; `real` = {1, 1} / {0, 0}: the patch sum (row g0 + g1, position 1)
-  // counts towards the bias unless the operands are formed behind the last tile
-  auto xf_u = [&](f32x2 (&U)[6], f32x2 real2) {
+  // U (both cout tiles): row pass t_j = gA_j + s gB_j, then A_w: 12 packed.  The patch sum (row g0 + g1, position 1) counts towards the bias --
+  // unless the operands are formed behind the last tile (realmask = 0: stale LDS contents, possibly NaN bit patterns: masked, not multiplied)
+  auto xf_u = [&](f32x2 (&U)[6], bool always, unsigned realmask) {
     const f32x2 k4 = {4.f, 4.f}, k2 = {2.f, 2.f}, kM2 = {-2.f, -2.f};
     f32x2 t[4], s02, s13, aa, b4;
 #pragma unroll
@@ -699,7 +708,14 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
     W24_PKADD(U[1], s02, s13); W24_PKSUB(U[2], s02, s13);
     W24_PKFMA(U[3], k2, b4, aa); W24_PKFMA(U[4], kM2, b4, aa);
     U[0] = t[0]; U[5] = t[3];
-    W24_PKFMA(bs2, real2, U[1], bs2);
+    if (always) {
+      W24_PKADD(bs2, bs2, U[1]);
+    } else {
+      // (as assembly: written as two scalar ANDs in C++, the compiler formed the first and COPIED it into the second half)
+      f32x2 u1m;
+      asm("v_and_b32 %0, %2, %3\n\tv_and_b32 %1, %2, %4" : "=&v"(u1m[0]), "=&v"(u1m[1]) : "s"(realmask), "v"(U[1][0]), "v"(U[1][1]));
+      W24_PKADD(bs2, bs2, u1m);
+    }
   };
   // V (both cin tiles): row pass d_j = dA_j + s dB_j, then B_w^T in 12: 18 packed
   auto xf_v = [&](f32x2 (&V)[6]) {
@@ -725,34 +741,43 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
   TileCtx c2;
   // dg / dx: how far the read pointers move behind this step's reads (to the k-step the NEXT call reads)
   auto kstep = [&](const f32x2 (&U)[6], const f32x2 (&V)[6], f32x2 (&UN)[6], f32x2 (&VN)[6], int dg, int dx,
-                   const TileCtx& dc, int db, int dj0, int djn, bool dlive, f32x2 real2, int mk = 0, bool mk_go = false) {
+                   const TileCtx& dc, int db, int dj0, int djn, bool dlive, bool always, unsigned realmask, int mk = 0, bool mk_go = false) {
+    unsigned pvo[9];
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
       mfma(i, U[i >> 2][(i >> 1) & 1], V[i >> 2][i & 1]);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef W24_NO_LDS        // (-DW24_NO_LDS / NO_XFORM / NO_DMA: timing-only ablation builds, tools/debug/build_w22_var.sh -- wrong results)
       if (i == 0) rd_g(false);
       if (i == 1) rd_g(true);
       if (i == 2) rd_d(0, false);
       if (i == 3) rd_d(3, false);
       if (i == 4) rd_d(0, true);
       if (i == 5) rd_d(3, true);
+#endif
       if (mk == 1 && i == 6) { pos_step(pos2, mk_go); ctx_offsets(pos2, c2); ctx_rsrcs(pos2, c2); }
       if (i == W24_RG) {
-        xf_u(UN, real2);
+#ifndef W24_NO_XFORM
+        xf_u(UN, always, realmask);
         xf_v(VN);
+#endif
         advance(dg, dx);
+#ifndef W24_NO_DMA
         if (djn > 0) {
           // (the lane parts of the piece offsets pass through here so that the pieces' vector-ALU work stays in THIS gap)
           asm volatile("" : "+v"(laneDy), "+v"(lpd), "+v"(laneX), "+v"(laneXw), "+v"(lpx), "+v"(lpxw));
 #pragma unroll
-          for (int u = 0; u < djn; ++u) piece(dc, db, dj0 + u, dlive);
+          for (int u = 0; u < djn; ++u) { pvo[u] = piece_off(dc, dj0 + u, dlive); asm volatile("" : "+v"(pvo[u])); }
         }
+#endif
       }
+#ifndef W24_NO_DMA
+      if (i > W24_RG && i - W24_RG - 1 < djn) piece_go(dc, db, dj0 + i - W24_RG - 1, pvo[i - W24_RG - 1]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  const f32x2 one2 = {1.f, 1.f};
   TileCtx cn;
   if (t_begin < t_end) {
     pos2 = tile_pos(t_begin);
@@ -770,7 +795,7 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
     if (t_begin + 1 < t_end) { piece(cn, 1, 0, true); piece(cn, 1, 1, true); }   // (the state every tile starts in: pieces 0, 1 of the next one issued)
     rd_g(false); rd_g(true);
     rd_d(0, false); rd_d(3, false); rd_d(0, true); rd_d(3, true);
-    xf_u(U0, one2);
+    xf_u(U0, true, 0u);
     xf_v(V0);
     advance(W24_DG, W24_DX);                                       // -> k-step 1 of buffer 0
   }
@@ -784,17 +809,33 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
     const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
     const int bnp = b ^ 1;
     const int flip = (b ? -1 : 1) * W22_TILE_FLOATS * 4;            // to the other buffer (bytes)
-    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 2, 5, more1, one2);            // runs step 0, reads step 1
-    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 7, 5, more1, one2);            // reads step 2
-    kstep(U0, V0, U1, V1, W24_DG3, W24_DX3, cn, bnp, 12, 4, more1, one2);         // reads step 3
-    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 16, 4, more1, one2);           // reads step 4
-    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 0, 0, false, one2, 1, more2);  // reads step 5
-    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 0, 0, false, one2);            // reads step 6
-    kstep(U0, V0, U1, V1, flip - W24_G7, flip - W24_X7, cn, bnp, 0, 0, false, one2);      // runs step 6, reads step 7; then on to step 0 of tile + 1
+#ifdef W24_DEAD_DMA         // (timing-only ablation: the pieces are issued, but out of range -- issue cost without memory traffic)
+    const bool plive = false;
+#else
+    const bool plive = more1;
+#endif
+#if W24_PIECE_PLAN == 1     // 6 + 6 + 6 on steps 0 - 2
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 2, 6, plive, true, 0u);            // runs step 0, reads step 1
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 8, 6, plive, true, 0u);            // reads step 2
+    kstep(U0, V0, U1, V1, W24_DG3, W24_DX3, cn, bnp, 14, 6, plive, true, 0u);         // reads step 3
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 0, 0, false, true, 0u);            // reads step 4
+#elif W24_PIECE_PLAN == 2   // 9 + 9 on steps 0, 1
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 2, 9, plive, true, 0u);
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 11, 9, plive, true, 0u);
+    kstep(U0, V0, U1, V1, W24_DG3, W24_DX3, cn, bnp, 0, 0, false, true, 0u);
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 0, 0, false, true, 0u);
+#else                       // 5 + 5 + 4 + 4 on steps 0 - 3
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 2, 5, plive, true, 0u);            // runs step 0, reads step 1
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 7, 5, plive, true, 0u);            // reads step 2
+    kstep(U0, V0, U1, V1, W24_DG3, W24_DX3, cn, bnp, 12, 4, plive, true, 0u);         // reads step 3
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 16, 4, plive, true, 0u);           // reads step 4
+#endif
+    kstep(U0, V0, U1, V1, W24_DG, W24_DX, cn, bnp, 0, 0, false, true, 0u, 1, more2);  // reads step 5
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, cn, bnp, 0, 0, false, true, 0u);            // reads step 6
+    kstep(U0, V0, U1, V1, flip - W24_G7, flip - W24_X7, cn, bnp, 0, 0, false, true, 0u);      // runs step 6, reads step 7; then on to step 0 of tile + 1
     __builtin_amdgcn_s_waitcnt(0x0070);                            // every piece of tile + 1 has landed (no other VMEM in flight)
     __builtin_amdgcn_s_barrier();
-    const f32x2 real2 = {more1 ? 1.f : 0.f, more1 ? 1.f : 0.f};
-    kstep(U1, V1, U0, V0, W24_DG, W24_DX, c2, b, 0, 2, more2, real2);             // runs step 7: pieces 0, 1 of tile + 2; first operands of tile + 1
+    kstep(U1, V1, U0, V0, W24_DG, W24_DX, c2, b, 0, 2, more2, false, more1 ? ~0u : 0u);             // runs step 7: pieces 0, 1 of tile + 2; first operands of tile + 1
     cn = c2;
     b ^= 1;
   }

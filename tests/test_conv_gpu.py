@@ -194,6 +194,7 @@ def test_conv_wgrad_wino22_forms(U, ci, co, h, w, n):
     try:
         for form in (1, 0, 2):
             L.lib().srk_debug_set_wgrad_w22_form(form)
+            L.poison_lds()               # (what a kernel reads of LDS bytes it never wrote must not reach a result)
             dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
             db = torch.full((co,), float("nan"), device="cuda")
             L.conv3x3_wgrad(L.View(U.nhwc(x)), L.View(U.nhwc(dy)), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co)

@@ -337,7 +337,8 @@ def test_inline_asm_mfma_hazards_of_the_wino42_kernel():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_w42_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 violation(s)" in r.stdout and "1440 v_mfma" in r.stdout
-    assert "1024 v_mfma instructions in the wino22 kernels" in r.stdout and "violation(s)" in r.stdout and r.stdout.count(": 0 violation(s)") == 2
+    # (4 x 256 in the wino22 kernels, 2 x 192 in wino24 -- its MFMAs are inline assembly too)
+    assert "1408 v_mfma instructions in the wino22 / wino24 kernels" in r.stdout and "violation(s)" in r.stdout and r.stdout.count(": 0 violation(s)") == 2
 
 
 def test_unknown_and_ignored_options_are_reported_once(capsys):

@@ -25,6 +25,7 @@ for (n, ci, co, h, w) in ((2, 64, 64, 16, 16), (2, 64, 64, 15, 17), (1, 128, 128
     xn, dn = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
     for form in (1, 2):
         L.lib().srk_debug_set_wgrad_w22_form(form)
+        L.poison_lds()
         dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda"); db = torch.full((co,), float("nan"), device="cuda")
         L.conv3x3_wgrad(L.View(xn), L.View(dn), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=ci, Cout=co)
         torch.cuda.synchronize()
@@ -38,6 +39,7 @@ dy = torch.nn.functional.pixel_unshuffle(g, 2)            # (n, 4F, h, w): chann
 gw, gb = ref(x, dy)
 for form in (1, 2):
     L.lib().srk_debug_set_wgrad_w22_form(form)
+    L.poison_lds()
     dw = torch.full((4 * F_, F_, 3, 3), float("nan"), device="cuda"); db = torch.full((4 * F_,), float("nan"), device="cuda")
     L.conv3x3_wgrad(L.View(x.permute(0, 2, 3, 1).contiguous()), L.View(g.permute(0, 2, 3, 1).contiguous()), dw, db, N=n, H=h, W=w, OH=h, OW=w, Cin=F_, Cout=4 * F_,
                     dy_mode=L.IN_UNSHUFFLE)
