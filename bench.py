@@ -363,6 +363,8 @@ def main():
         # F(2x4,3x3) (wino42): 24 instead of 72 per 2x4 output patch (1/3)
         if "wino42" in name:
             fac, what = 1.0 / 3.0, "2-D Winograd F(2x4, 3x3): F(4,3) along W times F(2,3) along H"
+        elif "wino24" in name:
+            fac, what = 1.0 / 3.0, "2-D transposed Winograd F(2,3) along H x F(4,3) along W"
         elif "wino22" in name:
             fac, what = 4.0 / 9.0, "2-D transposed Winograd F(2,3) x F(2,3)"
         else:
