@@ -219,9 +219,11 @@ int srk_debug_set_conv_small(int mode);
 /* Test aid: M tiles per workgroup of the F(2x4, 3x3) conv kernel (wp_format 6): 0 = by launch size (default), 1 = 16-row tiles,
  * 2 = 32-row tiles. */
 int srk_debug_set_wino42_nmt(int nmt);
-/* Test aid: form of the 2-D Winograd weight-gradient kernel (fp32, stride 1, > 32 channels each way): 1 = row-owner form (default:
- * each wave of a workgroup owns one row of the 4 x 4 transform positions for the whole 64 x 64 chunk), 0 = tile-owner form (each
- * wave owns all 16 positions of a 32 x 32 tile), < 0 = back to the default / SRK_WGRAD_W22_FORM. */
+/* Test aid: form of the 2-D Winograd weight-gradient kernel (fp32, stride 1, > 32 channels each way): 2 = wino24 (default since round 4:
+ * transposed F(2,3) along H x F(4,3) along W, a third of the direct kernel's MFMAs; each wave owns one row of the 4 x 6 transform
+ * positions for the whole 64 x 64 chunk), 1 = wino22, row-owner form (F(2,3) both ways, 4/9 of the MFMAs; one row of the 4 x 4 positions
+ * per wave), 0 = wino22, tile-owner form (each wave owns all 16 positions of a 32 x 32 tile), < 0 = back to the default /
+ * SRK_WGRAD_W22_FORM. */
 int srk_debug_set_wgrad_w22_form(int rows);
 /* Measurement aid: writes the name (as rocprofv3 prints it) of the kernel srk_conv3x3 dispatches to for these arguments into
  * buf (NUL-terminated, truncated to len).  Launches nothing. */

@@ -636,6 +636,11 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
   // per MFMA gap behind it -- back to back they queue in the address unit (measured on the conv kernel: five in a row ~180 cycles each; here:
   // 45 us of a 480 us launch with all of a step's pieces in one gap).
   auto piece_off = [&](const TileCtx& c, int j, bool live) -> unsigned {
+#ifdef W24_CHEAP_PIECES      // (timing-only ablation: one add per piece, no validity tests, no row-wrap select.  NOT a measure of the offsets' cost:
+                             //  the pieces then fetch the same few lines -- 467 -> 425 us; a correct form with half the vector-ALU work: 470 -> 466)
+    if (j < 8) return laneDy + c.org_dy + (unsigned)j * dyRow;
+    return laneX + c.org_x + (unsigned)((4 * (j - 8) + wv) * 16);
+#endif
     if (j < 8) {
       const unsigned so = c.org_dy + (unsigned)j * dyRow;
       const int ow = live ? c.ow0 : (1 << 28);
