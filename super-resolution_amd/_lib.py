@@ -202,6 +202,14 @@ def chain_recover() -> int:
     return rc
 
 
+_POISON = os.environ.get("SRK_POISON_LDS", "0") == "1"      # test runs: NaN patterns into every CU's LDS in front of every conv / weight-gradient launch
+
+
+def _poison():
+    if _POISON:
+        poison_lds()
+
+
 def poison_lds():
     """test aid (srk_debug_poison_lds): NaN bit patterns into the whole LDS of every CU, on the current stream"""
     check(lib().srk_debug_poison_lds(stream_ptr()), "srk_debug_poison_lds")
@@ -363,6 +371,7 @@ def conv3x3(x: View, wp: torch.Tensor, bias, y: View, **kw):
         check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
         e1.record()
         return
+    _poison()
     check(lib().srk_conv3x3(C.byref(a), stream_ptr()), "srk_conv3x3")
 
 
@@ -390,6 +399,7 @@ def conv3x3_seq(calls):
         check(lib().srk_conv3x3_seq(arr, n, stream_ptr()), "srk_conv3x3_seq")
         e1.record()
         return
+    _poison()
     check(lib().srk_conv3x3_seq(arr, n, stream_ptr()), "srk_conv3x3_seq")
 
 
@@ -442,6 +452,7 @@ def conv3x3_wgrad(x: View, dy: View, dw: torch.Tensor, db, **kw):
         check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
         e1.record()
         return
+    _poison()
     check(lib().srk_conv3x3_wgrad(C.byref(a), stream_ptr()), "srk_conv3x3_wgrad")
 
 
@@ -493,6 +504,7 @@ def conv3x3_wgrad_batched(problems, *, N, H, W, OH, OW, stride=1, dy_mode=IN_PLA
         check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
         e1.record()
         return
+    _poison()
     check(lib().srk_conv3x3_wgrad_batched(arr, n, stream_ptr()), "srk_conv3x3_wgrad_batched")
 
 
