@@ -643,10 +643,16 @@ __global__ __launch_bounds__(W22_THREADS) void wgrad_f32_wino24_kernel(const WBa
 #endif
     if (j < 8) {
       const unsigned so = c.org_dy + (unsigned)j * dyRow;
+#ifdef W24_DEAD_DY          // (timing-only ablations: only the dy / only the x pieces fetch)
+      live = false;
+#endif
       const int ow = live ? c.ow0 : (1 << 28);
       const bool ok = (unsigned)(lpd + ow) < (unsigned)B.OW;
       return ok ? laneDy + so : W_OOB;
     }
+#ifdef W24_DEAD_X
+    live = false;
+#endif
     const int k = 4 * (j - 8) + wv, hp0 = 4 * k, ar = hp0 / W22_IW, bq = hp0 - W22_IW * ar;
     const bool isw = bq == 16;
     const unsigned so = c.org_x + (unsigned)(((ar - 1) * B.W + bq - 1) * a.x_ldc * 4);
